@@ -1,0 +1,237 @@
+"""The CPU oracle (oracle/daisy_oracle.py) against the golden vectors generated from the reference
+(tests/golden/make_golden.py).  This is what pins the oracle: SURVEY.md §8(c) G1-G9."""
+import numpy as np
+import pytest
+
+from oracle import daisy_oracle as O
+
+
+def _assert_initial_grid(got, ref):
+    """The initial grid is NOT quantised (ref :304-324): covers are exact, the three temperature
+    channels carry the reference's ~1e-13 FFT noise."""
+    assert np.array_equal(got[:, :3], ref[:, :3])
+    np.testing.assert_allclose(got[:, 3:6], ref[:, 3:6], rtol=1e-12, atol=0)
+    assert np.array_equal(got[:, 6], ref[:, 6])
+
+
+def _env(dim, n_agents, batch, **kw):
+    return O.OracleDaisyWorld(grid_dimension=dim, n_agents=n_agents, batch_size=batch, **kw)
+
+
+def test_g6_direct_stencil_equals_ft_convolve(golden):
+    g = golden("G6_ft_convolve")
+    k = g["kernel"]
+    for i in range(int(g["n"])):
+        y = O.toroidal_conv3x3(g[f"x_{i}"], k[0, 0])
+        np.testing.assert_allclose(y, g[f"y_{i}"], rtol=0, atol=5e-15)
+
+
+def test_g6_neighborhood_masks(golden):
+    g = golden("G6_ft_convolve")
+    for mode in ("moore", "von_neumann", "circular", "asdf"):
+        for r in (1, 2, 3, 4):
+            assert np.array_equal(O.neighborhood_mask(r, mode), g[f"nbhd_{mode}_{r}"])
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_g1_forward(golden, tag):
+    g = golden("G1_forward")
+    env = _env(16, 2, 2)
+    env.L = float(g[f"{tag}_L"])
+    env.agent_indices = g[f"{tag}_agent_indices"].copy()
+    env.agent_states = g[f"{tag}_agent_states"].copy()
+    out = env.forward(g[f"{tag}_grid_in"].copy())
+    ref = g[f"{tag}_grid_out"]
+    # light/dark/bare: bit-exact after the 3-decimal quantiser
+    assert np.array_equal(out[:, :3], ref[:, :3])
+    # rounded temperature channels: identical up to one quantum on a measure-zero set; exact here
+    assert np.array_equal(out[:, 3:], ref[:, 3:])
+    for name in ("temp", "temp_light", "temp_dark", "temp_effective", "beta", "beta_l", "beta_d",
+                 "growth", "dead_temp"):
+        np.testing.assert_allclose(getattr(env, name), g[f"{tag}_{name}"], rtol=1e-12, atol=1e-12)
+
+
+def test_g2_c1_trajectory(golden):
+    g = golden("G2_c1_trajectory")
+    env = _env(64, 0, 1)
+    env.set_initial_cover(g["light0"], g["dark0"])
+    env.agent_indices = np.zeros((1, 0, 2), dtype=np.int64)
+    env.agent_states = np.ones((1, 0, 1))
+    snaps = set(int(s) for s in g["snap_steps"])
+    for t in range(1, 501):
+        assert env.L == g["L_used"][t - 1]
+        obs, reward, done, _ = env.step()
+        assert env.grid[:, 1].mean() == g["mean_light"][t - 1]
+        assert env.grid[:, 2].mean() == g["mean_dark"][t - 1]
+        assert abs(env.temp.mean() - g["mean_temp"][t - 1]) < 1e-9
+        assert env.dead_temp[0] == pytest.approx(g["dead_temp"][t - 1], rel=1e-14)
+        assert np.array_equal(reward, g["reward"][t - 1])
+        assert np.array_equal(done, g["done"][t - 1])
+        if t in snaps:
+            assert np.array_equal(np.rint(env.grid[:, 1] * 1000).astype(np.uint16), g[f"light_k_{t}"])
+            assert np.array_equal(np.rint(env.grid[:, 2] * 1000).astype(np.uint16), g[f"dark_k_{t}"])
+            assert np.array_equal(env.grid[:, 3:6], g[f"temp3_{t}"])
+            assert np.array_equal(env.grid[:, 0], g[f"bare_{t}"])
+    assert env.L == float(g["final_L"])
+    assert tuple(obs.shape) == tuple(g["obs_shape"])
+
+
+def _g3_actions(g):
+    acts = []
+    for t in range(int(g["n_steps"])):
+        acts.append(None if f"action_{t}_none" in g.files else g[f"action_{t}"])
+    return acts
+
+
+def test_g3_agents(golden):
+    g = golden("G3_agents")
+    env = _env(8, 4, 4)
+    env.L = float(g["L0"])
+    env.set_initial_cover(g["light0"], g["dark0"])
+    env.L = float(g["L0"])
+    env.agent_indices = g["agent_indices0"].copy()
+    env.agent_states = g["agent_states0"].copy()
+    for t, a in enumerate(_g3_actions(g)):
+        obs, reward, done, _ = env.step(a)
+        assert np.array_equal(env.agent_indices, g["agent_indices"][t]), t
+        assert np.array_equal(env.agent_states, g["agent_states"][t]), t
+        assert np.array_equal(env.grid[:, 1], g["light"][t]), t
+        assert np.array_equal(env.grid[:, 2], g["dark"][t]), t
+        assert np.array_equal(obs, g["obs"][t]), t
+        assert np.array_equal(reward, g["reward"][t]), t
+        assert np.array_equal(done, g["done"][t]), t
+        assert env.L == g["L_after"][t]
+    assert np.array_equal(env.grid, g["grid_final"])
+
+
+def test_g4_greedy(golden):
+    g = golden("G4_greedy")
+    obs = g["obs"]
+    assert np.array_equal(O.OracleGreedy()(obs), g["greedy"])
+    assert np.array_equal(O.OracleGreedy(greedy=False)(obs), g["antigreedy"])
+    for eps in (0.0, 0.5, 1.0):
+        np.random.seed(1234)
+        agent = O.OracleGreedy(epsilon=eps)
+        seq = np.array([agent(obs) for _ in range(12)])
+        assert np.array_equal(seq, g[f"eps_{eps}_seq"])
+
+
+@pytest.mark.parametrize("agent_status,daisy_status", [
+    ("greedy", "light_and_dark"), ("antigreedy", "light_and_dark"), ("random", "neutral_albedo"),
+    ("half_random", "light_and_dark"), ("no", "light_and_dark")])
+def test_g5_lifespans(golden, agent_status, daisy_status):
+    g = golden("G5_lifespans")
+    B, seed = int(g["B"]), int(g["seed"])
+    np.random.seed(seed)
+    env = O.OracleDaisyWorld.like_reference_ctor(grid_dimension=8)
+    env.P.batch_size = B
+    if daisy_status == "neutral_albedo":
+        env.P.albedo_dark = env.P.albedo_light = env.P.albedo_bare
+    agent = {"greedy": O.OracleGreedy(0.0), "antigreedy": O.OracleGreedy(0.0, greedy=False),
+             "random": O.OracleGreedy(1.0), "half_random": O.OracleGreedy(0.5), "no": None}[agent_status]
+    env.reset()
+    done_at, agents_done_at = O.simulate_lifespan(env, agent)
+    key = f"{agent_status}_{daisy_status}"
+    assert np.array_equal(done_at, g[key + "_done_at"])
+    assert np.array_equal(agents_done_at, g[key + "_agents_done_at"])
+
+
+def test_g7_no_agents(golden):
+    g = golden("G7_no_agents")
+    env = _env(12, 0, 3)
+    env.set_initial_cover(g["light0"], g["dark0"])
+    _assert_initial_grid(env.grid, g["grid0"])
+    env.agent_indices = np.zeros((3, 0, 2), dtype=np.int64)
+    env.agent_states = np.ones((3, 0, 1))
+    for t in range(6):
+        obs, reward, done, _ = env.step()
+        assert reward.dtype == np.bool_ and str(g["reward_dtype"]) == "bool"
+        assert np.array_equal(reward, g["reward"][t])
+        assert np.array_equal(done, g["done"][t])
+        assert np.array_equal(env.grid, g["grids"][t])
+    assert tuple(obs.shape) == tuple(g["obs_shape"]) == (3, 0, 7, 3, 3)
+    assert env.L == float(g["L_final"]) and env.step_count == int(g["step_count"])
+    env.grid[1, 1:3] = 0.0
+    obs, reward, done, _ = env.step()
+    assert np.array_equal(reward, g["dead_reward"]) and np.array_equal(done, g["dead_done"])
+
+
+def test_g8_collisions(golden):
+    g = golden("G8_collisions")
+    env = _env(5, 4, 3, collision_mode=1)
+    env.set_initial_cover(g["light0"], g["dark0"])
+    env.agent_indices = g["agent_indices0"].copy()
+    env.agent_states = g["agent_states0"].copy()
+    np.random.seed(int(g["jitter_seed"]))
+    for t in range(6):
+        env.step(np.full((3, 4, 1), 8))
+        assert np.array_equal(env.agent_indices, g["agent_indices"][t])
+        np.testing.assert_array_equal(env.agent_states, g["agent_states"][t])
+    assert np.array_equal(env.grid, g["grid_final"])
+
+
+def test_g9_ctor_rng_order(golden):
+    g = golden("G9_ctor_rng_order")
+    np.random.seed(int(g["seed"]))
+    env = O.OracleDaisyWorld.like_reference_ctor(grid_dimension=16)
+    _assert_initial_grid(env.grid, g["ctor_grid"])
+    assert np.array_equal(env.agent_indices, g["ctor_agent_indices"])
+    assert env.dL == float(g["ctor_dL"]) and env.L == float(g["ctor_L"])
+    env.P.batch_size, env.P.n_agents = 5, 3
+    env.P.albedo_light, env.P.min_L, env.P.ramp_period = 0.7, 0.8, 100
+    obs = env.reset()
+    _assert_initial_grid(env.grid, g["reset_grid"])
+    assert np.array_equal(env.agent_indices, g["reset_agent_indices"])
+    np.testing.assert_allclose(obs, g["reset_obs"], rtol=1e-12, atol=0)
+    assert env.dL == float(g["reset_dL"]) and env.L == float(g["reset_L"])
+    obs, reward, done, _ = env.step(np.random.randint(9, size=(5, 3, 1)))
+    assert np.array_equal(obs, g["step_obs"])
+    assert np.array_equal(reward, g["step_reward"]) and np.array_equal(done, g["step_done"])
+    assert np.array_equal(env.grid, g["step_grid"])
+    assert env.L == float(g["step_L"])
+
+
+# ---- the C restatement (oracle/daisy_oracle.c) ------------------------------------------------
+def test_c_oracle_g1_forward(golden):
+    from oracle import c_oracle
+    g = golden("G1_forward")
+    for tag in "abc":
+        gi = g[f"{tag}_grid_in"]
+        out, caches = c_oracle.forward(gi[:, 1], gi[:, 2], float(g[f"{tag}_L"]), want_caches=True)
+        ref = g[f"{tag}_grid_out"].copy()
+        # the fixture has agent states written into channel 4 at agent cells (ref :454-459)
+        idx = g[f"{tag}_agent_indices"]
+        for bb in range(idx.shape[0]):
+            for nn in range(idx.shape[1]):
+                out[bb, 4, idx[bb, nn, 0], idx[bb, nn, 1]] = g[f"{tag}_agent_states"][bb, nn, 0]
+        assert np.array_equal(out, ref)
+        np.testing.assert_allclose(caches[:, 0], g[f"{tag}_temp"][:, 0], rtol=1e-12)
+        np.testing.assert_allclose(caches[:, 5:7], g[f"{tag}_growth"], rtol=1e-9, atol=1e-15)
+
+
+def test_c_oracle_g2_trajectory(golden):
+    from oracle import c_oracle
+    g = golden("G2_c1_trajectory")
+    light, dark = g["light0"].copy(), g["dark0"].copy()
+    L, dL, t = 0.75, 0.75 / 512, 0
+    for snap in (int(s) for s in g["snap_steps"]):
+        L = c_oracle.step_n(light, dark, L, dL, snap - t)
+        t = snap
+        assert np.array_equal(np.rint(light * 1000).astype(np.uint16), g[f"light_k_{t}"])
+        assert np.array_equal(np.rint(dark * 1000).astype(np.uint16), g[f"dark_k_{t}"])
+    assert L == float(g["final_L"])
+
+
+def test_c_oracle_matches_numpy_oracle_multiworld():
+    from oracle import c_oracle
+    rng = np.random.RandomState(0)
+    B, H, W = 5, 9, 12
+    light = np.rint(rng.rand(B, H, W) * 400) / 1000
+    dark = np.rint(rng.rand(B, H, W) * 400) / 1000
+    env = O.OracleDaisyWorld(grid_dimension=H, n_agents=0, batch_size=B)
+    env.L = 1.03
+    grid = np.zeros((B, 7, H, W))
+    grid[:, 1], grid[:, 2] = light, dark
+    ref = env.forward(grid)
+    out = c_oracle.forward(light, dark, 1.03)
+    assert np.array_equal(out, ref)
