@@ -1,0 +1,246 @@
+/* daisyworld_hip.h — C ABI of libdaisyworld_hip.so, the MI355X (gfx950) implementation of the
+ * RLDaisyWorld grid-update hot path.
+ *
+ * The reference (riveSunder/therldaisyworld) is pure Python/NumPy and has no FFI layer: the
+ * "operator interface" of this path is the method surface of class RLDaisyWorld in
+ * daisy/daisy_world_rl.py.  Each entry point below therefore cites the reference method
+ * (file:line) whose work it performs.  The Python drop-in therldaisyworld_amd.RLDaisyWorld binds
+ * these functions with ctypes (see INTEGRATION.md for the stub a reference maintainer would add).
+ *
+ * Conventions
+ *   - plain C: opaque handle, plain pointers and sizes; no C++/torch types cross the boundary.
+ *   - every function returns DW_OK (0) or a negative DW_E* code and never throws; the message of
+ *     the last failure on the calling thread is returned by dw_last_error().
+ *   - the caller owns every host buffer (C-contiguous); the library owns all device memory inside
+ *     the handle and frees it in dw_destroy().
+ *   - a handle is bound to one HIP device and one stream; it is not thread-safe, distinct handles
+ *     may be used from distinct threads / processes (one process per GPU for ensemble shards).
+ *   - dw_step*, dw_policy_* and dw_init_random are asynchronous on the handle's stream; every
+ *     function that returns data to the host synchronises that stream first.
+ *   - there is NO CPU fallback: on a machine without a usable HIP device dw_create() fails with
+ *     DW_ENODEVICE.
+ *
+ * Layout
+ *   grids are row-major [world][row][col]; "row" is the reference's axis -2 (which its code calls
+ *   x) and "col" its axis -1 (y).  Device state is two planar float32 arrays per buffer (light,
+ *   dark) holding the cover in PER-MILLE units (1000 * cover; exactly the integers 0..1000 once a
+ *   step has run, because the reference quantises to 3 decimals, daisy_world_rl.py:452), kept
+ *   ping-pong so that the pre-step state stays available for observations / materialisation.
+ */
+#ifndef DAISYWORLD_HIP_H
+#define DAISYWORLD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DW_ABI_VERSION 1
+
+/* ---- error codes ---------------------------------------------------------------------------- */
+enum {
+    DW_OK = 0,
+    DW_EINVAL = -1,     /* bad argument (null pointer, shape mismatch, unsupported size) */
+    DW_ENODEVICE = -2,  /* no usable HIP device / wrong architecture */
+    DW_ENOMEM = -3,     /* device or host allocation failed */
+    DW_EHIP = -4,       /* a HIP runtime call failed (message has the HIP error string) */
+    DW_ESTATE = -5      /* call not valid in the handle's current state (e.g. step before upload) */
+};
+
+/* ---- arithmetic modes ----------------------------------------------------------------------- */
+enum {
+    /* float32 arithmetic with a float64 re-evaluation of every cell whose pre-rounding value lies
+     * within a proven error bound of a rounding tie: results are bit-identical to float64
+     * evaluation of the reference formulas (the default). */
+    DW_PRECISION_EXACT = 0,
+    /* float32 arithmetic only: every cell within one quantum (1e-3) of the float64 result and
+     * >= 99.5 % of cells identical after one step from the same state. */
+    DW_PRECISION_FAST = 1,
+    /* float64 arithmetic for every cell (slow; the in-library reference the other two are tested
+     * against, and the path used for the first step from an un-quantised initial state). */
+    DW_PRECISION_F64 = 2
+};
+
+/* which of the two retained states a download refers to */
+enum { DW_STATE_CURRENT = 0, DW_STATE_PREVIOUS = 1 };
+
+/* scripted policy modes for dw_policy_greedy (ref: daisy/agents/greedy.py:14-36) */
+enum { DW_POLICY_ARGMAX = 0, DW_POLICY_ARGMIN = 1 };
+
+typedef struct dw_handle dw_handle;
+
+/* Construction-time shape + the physics constants of RLDaisyWorld.__init__
+ * (ref: daisy_world_rl.py:18-79).  Shapes are fixed for the life of the handle; the constants can
+ * be changed later with dw_set_params (the reference lets callers assign attributes and then call
+ * reset(), e.g. notebooks/greedy_longevity_abatement.ipynb cell 2:3-8). */
+typedef struct dw_params {
+    int32_t abi_version;      /* must be DW_ABI_VERSION */
+    int32_t batch;            /* B: worlds in this handle (ref batch_size, :20) */
+    int32_t height;           /* H = grid_dimension (:29) */
+    int32_t width;            /* W = grid_dimension; H != W is allowed (ft_convolve accepts it) */
+    int32_t n_agents;         /* N agents per world (:79); 0 allowed */
+    int32_t device;           /* HIP device ordinal */
+    int32_t precision;        /* DW_PRECISION_* */
+    int32_t obs_mask;         /* 9-bit row-major 3x3 neighbourhood mask applied to observations
+                                 (bit 4 = centre); von Neumann = 0x0BA, Moore = 0x1FF
+                                 (ref: nn/functional.py:51-103, daisy_world_rl.py:261) */
+    int32_t collision_mode;   /* 0 or 1 (ref :44, :220-242) */
+    int32_t reserved0;
+    int64_t world_offset;     /* global id of world 0 of this shard; keys the device RNG so that an
+                                 ensemble sharded over GPUs draws the same worlds as a single run */
+    double p, g, S, sigma, gamma, q, q2, dt;                         /* ref :32-52 */
+    double albedo_bare, albedo_light, albedo_dark, temp_optimal;     /* ref :65-69 */
+    double agent_gamma, food_chain_penalty;                          /* ref :55, :70 */
+    double initial_al, initial_ad, light_proportion, dark_proportion;/* ref :73-77 */
+} dw_params;
+
+/* Per-world reductions fused into every step: the callers' lifespan test
+ * `grid[:,1:3].max((1,2,3)) <= 0.005` (notebook greedy_longevity_abatement cell 2:48), the no-agent
+ * reward `grid[:,1:3].sum((-2,-1)) > 0` (ref :489) and the population means.  All integers, in
+ * per-mille units, hence exact and order-independent. */
+typedef struct dw_world_stats {
+    uint32_t max_k;        /* max over light and dark cells of 1000*cover */
+    uint32_t reserved;
+    uint64_t sum_light_k;  /* sum over cells of 1000*light */
+    uint64_t sum_dark_k;   /* sum over cells of 1000*dark  */
+} dw_world_stats;
+
+/* ---- life cycle ----------------------------------------------------------------------------- */
+
+/* Fill *p with the reference's default constants for the given shape (ref :18-79). */
+int dw_default_params(dw_params* p, int32_t batch, int32_t height, int32_t width, int32_t n_agents);
+
+/* Create a handle (allocates device state).  ref: RLDaisyWorld.__init__ :15-83 (without the RNG
+ * draws, which stay on the host in the shim for same-seed parity, or use dw_init_random). */
+int dw_create(const dw_params* p, dw_handle** out);
+int dw_destroy(dw_handle* h);
+
+/* Replace the physics constants (shape / device fields must match the handle's). */
+int dw_set_params(dw_handle* h, const dw_params* p);
+int dw_get_params(const dw_handle* h, dw_params* out);
+
+const char* dw_last_error(void);
+int dw_abi_version(void);
+
+/* ---- state in / out ------------------------------------------------------------------------- */
+
+/* Upload an initial cover state, cover fractions in natural units [B][H][W] float64; the state is
+ * treated as NOT quantised (ref initialize_grid :285-324 does not round), so the next step is
+ * evaluated in float64 from these exact values.  Resets the retained "previous" state. */
+int dw_upload_state_f64(dw_handle* h, const double* light, const double* dark);
+
+/* Same from float32 natural-unit planes.  quantised != 0 asserts every value is k/1000. */
+int dw_upload_state_f32(dw_handle* h, const float* light, const float* dark, int quantised);
+
+/* Agent positions [B][N][2] (row, col) and energy stores [B][N] (ref initialize_agents :173-179). */
+int dw_upload_agents(dw_handle* h, const int32_t* indices, const double* states);
+int dw_download_agents(dw_handle* h, int32_t* indices, double* states);
+
+/* Synthetic initial state generated on the device with a counter-based RNG (Philox4x32-10 keyed by
+ * seed, global world id and cell), same distribution as ref initialize_grid :287-302 and
+ * initialize_agents :175-179: cover = [U1 < proportion] * initial_a * U2 per species, agents at
+ * uniform cells with state 1.  Used for the large synthetic configurations. */
+int dw_init_random(dw_handle* h, uint64_t seed);
+
+/* Download light/dark cover of the current or previous state in natural units, [B][H][W] float64
+ * (either pointer may be NULL). */
+int dw_download_planes(dw_handle* h, int which, double* light, double* dark);
+
+/* Materialise the reference's 7-channel grid `self.grid` [B][7][H][W] float64 for the current
+ * state: after a step = exactly ref forward() :445-459 (rounded covers and bare, rounded
+ * temperatures of the pre-step state, agent states written into channel 4); after an upload = ref
+ * initialize_grid :304-323 (un-rounded).  L_init is used only in the second case. */
+int dw_download_grid(dw_handle* h, double L_init, double* grid7);
+
+/* Side-effect caches of the last physics pass, each optional (NULL to skip):
+ * temps [B][3][H][W] = temp, temp_light, temp_dark (un-rounded; ref :415-419),
+ * betas [B][3][H][W] = beta, beta_l, beta_d (ref :345-347), growth [B][2][H][W] (ref :373),
+ * temp_effective [B][H][W] (ref :404).  L is the luminosity of that pass. */
+int dw_download_caches(dw_handle* h, double L, double* temps, double* betas, double* growth,
+                       double* temp_effective);
+
+/* ---- the hot path --------------------------------------------------------------------------- */
+
+/* One environment step with luminosity L (ref step :475-497 minus update_L, which stays on the
+ * host as a float64 scalar recurrence, :463-473):
+ *   1. if action != NULL: update_agents (ref :181-244) for the leading action_b x action_n block
+ *      of agents, host int32 actions [action_b][action_n] (codes 0..8);
+ *   2. grid = forward(grid) (ref :434-461) as one fused stencil + reaction kernel;
+ *   3. per-world reductions (dw_world_stats).
+ * Asynchronous. */
+int dw_step(dw_handle* h, const int32_t* action, int32_t action_b, int32_t action_n, double L);
+
+/* Same, taking the actions from the handle's device action buffer (filled by dw_policy_greedy or
+ * dw_upload_actions) — keeps an episode loop free of host round trips. */
+int dw_step_device_actions(dw_handle* h, double L);
+int dw_upload_actions(dw_handle* h, const int32_t* action /* [B][N] */);
+int dw_download_actions(dw_handle* h, int32_t* action /* [B][N] */);
+
+/* `nsteps` consecutive steps with the reference's luminosity recurrence L <- clamp(L + dL)
+ * (ref :471-473) evaluated on the host in float64, *L_io updated.  use_device_actions: 0 = no
+ * update_agents call at all (ref `action is None` with n_agents == 0), 1 = actions are taken from
+ * the device action buffer every step (constant unless a policy refreshes it). */
+int dw_step_n(dw_handle* h, int32_t nsteps, double* L_io, double dL, double min_L, double max_L,
+              int use_device_actions);
+
+/* update_agents alone (ref :181-244) and forward alone on caller data (ref :434-461): the latter
+ * is stateless w.r.t. the cover planes: host covers [B][H][W] float64 in, 7-channel grid out
+ * (agent states of the handle are written into channel 4 as the reference does); the optional
+ * cache outputs are those of dw_download_caches for that input. */
+int dw_update_agents(dw_handle* h, const int32_t* action, int32_t action_b, int32_t action_n);
+int dw_forward_f64(dw_handle* h, const double* light, const double* dark, double L, double* grid7,
+                   double* temps, double* betas, double* growth, double* temp_effective);
+
+/* Observations (ref get_obs :246-263): [B][N][7][3][3] float64 for the handle's agents, taken from
+ * the current grid exactly as dw_download_grid would materialise it, times the neighbourhood mask. */
+int dw_get_obs(dw_handle* h, double L_init, double* obs);
+
+/* reward [B][N] float64 and done [B][N] uint8 as ref step :486-492 (N > 0). */
+int dw_get_reward_done(dw_handle* h, double* reward, uint8_t* done);
+
+/* Per-world reductions of the current state (always up to date after a step). */
+int dw_reduce(dw_handle* h, dw_world_stats* per_world /* [B] */);
+
+/* Scripted policy on the device (ref Greedy.__call__ agents/greedy.py:14-36): fills the device
+ * action buffer from the current observations.  mode: DW_POLICY_ARGMAX -> 4+argmax of light+dark
+ * over the candidates (row,col-1),(row-1,col),(row+1,col),(row,col+1) (= flat 3x3 indices 3,1,7,5),
+ * first maximum wins; DW_POLICY_ARGMIN -> 4+argmin.  The epsilon (uniformly random) branch is
+ * drawn by the caller (so that the legacy NumPy stream stays on the host) and handed over with
+ * dw_upload_actions. */
+int dw_policy_greedy(dw_handle* h, int mode);
+
+/* Device-resident lifespan harness (ref notebooks/greedy_longevity_abatement.ipynb cell 2:28-57):
+ * accumulate done_at[b] += (max_k > threshold_k) and agents_done_at[b][n] += !(done) after each
+ * step, on the device.  dw_lifespan_reset zeroes them. */
+int dw_lifespan_reset(dw_handle* h);
+int dw_lifespan_accumulate(dw_handle* h, uint32_t threshold_k);
+int dw_lifespan_download(dw_handle* h, int32_t* done_at /* [B] */, int32_t* agents_done_at /* [B][N] */,
+                         int32_t* n_worlds_alive);
+
+/* ---- plumbing ------------------------------------------------------------------------------- */
+
+/* Use an existing HIP stream (e.g. torch's current stream) instead of the handle's own. */
+int dw_set_stream(dw_handle* h, void* hip_stream);
+int dw_sync(dw_handle* h);
+
+/* HIP-event timing on the handle's stream: ms between start and stop (stop synchronises). */
+int dw_timer_start(dw_handle* h);
+int dw_timer_stop(dw_handle* h, float* elapsed_ms);
+
+/* Raw device pointers of the current planes (per-mille float32, [B][H][W]) for zero-copy interop. */
+int dw_device_planes(dw_handle* h, int which, void** light, void** dark);
+
+/* Name and geometry of the step kernel the handle dispatches for its shape, for bench/profiles:
+ * writes a NUL-terminated description into buf. */
+int dw_kernel_info(dw_handle* h, char* buf, size_t buflen);
+
+/* Diagnostics for the exact-mode error bound: number of cells re-evaluated in float64 by the last
+ * step (summed over worlds). */
+int dw_last_fixup_count(dw_handle* h, uint64_t* count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DAISYWORLD_HIP_H */

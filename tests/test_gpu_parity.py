@@ -1,0 +1,416 @@
+"""GPU parity tests (run with ``-m gpu`` on an MI355X): the HIP path, called through the C ABI,
+against the CPU oracle and the golden vectors generated from the reference.
+
+Bars:
+  * DW_PRECISION_F64 and DW_PRECISION_EXACT: light/dark planes BIT-EXACT against the float64 oracle
+    (integers k = 1000*cover compared), single steps and whole trajectories;
+  * DW_PRECISION_FAST: every cell within one quantum (1e-3) and >= 99.5 % of cells identical after
+    one step from the same state;
+  * agents / observations / rewards: exact equality with the reference fixtures (float64).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import c_oracle  # noqa: E402
+from oracle import daisy_oracle as O  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import therldaisyworld_amd as t
+    return t
+
+
+def _engine(amd, B, H, W, N=0, precision="exact", **over):
+    from therldaisyworld_amd import _ffi
+    p = amd.default_params(B, H, W, N)
+    p.precision = _ffi.PRECISION[precision]
+    for k, v in over.items():
+        setattr(p, k, v)
+    return amd.Engine(p)
+
+
+def _random_quantised(rng, B, H, W, hi=400, sparsity=0.3):
+    light = np.rint(rng.rand(B, H, W) * hi) * (rng.rand(B, H, W) > sparsity)
+    dark = np.rint(rng.rand(B, H, W) * hi) * (rng.rand(B, H, W) > sparsity)
+    tot = light + dark
+    scale = np.where(tot > 1000, 1000.0 / np.maximum(tot, 1), 1.0)
+    return np.floor(light * scale) / 1000.0, np.floor(dark * scale) / 1000.0
+
+
+def _k(x):
+    return np.rint(np.asarray(x) * 1000.0).astype(np.int64)
+
+
+def _oracle_params(**over):
+    return c_oracle.OracleParams.defaults(**over)
+
+
+# ---------------------------------------------------------------------------------------------
+# forward() on caller data: fixture G1 (generated from the reference)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_forward_matches_reference_fixture_g1(amd, golden, tag):
+    g = golden("G1_forward")
+    gi = g[f"{tag}_grid_in"]
+    eng = _engine(amd, 2, 16, 16, 2)
+    eng.upload_agents(g[f"{tag}_agent_indices"], g[f"{tag}_agent_states"][..., 0])
+    grid, t, b, gr, e = eng.forward(gi[:, 1], gi[:, 2], float(g[f"{tag}_L"]), want_caches=True)
+    ref = g[f"{tag}_grid_out"]
+    assert np.array_equal(grid[:, :3], ref[:, :3])          # bare/light/dark: bit-exact
+    assert np.array_equal(grid[:, 3:], ref[:, 3:])          # rounded temps + agent stamps + ch6
+    np.testing.assert_allclose(t[:, 0:1], g[f"{tag}_temp"], rtol=1e-12)
+    np.testing.assert_allclose(t[:, 1:2], g[f"{tag}_temp_light"], rtol=1e-12)
+    np.testing.assert_allclose(t[:, 2:3], g[f"{tag}_temp_dark"], rtol=1e-12)
+    np.testing.assert_allclose(e, g[f"{tag}_temp_effective"], rtol=1e-12)
+    np.testing.assert_allclose(b[:, 0:1], g[f"{tag}_beta"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(b[:, 1:2], g[f"{tag}_beta_l"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(gr, g[f"{tag}_growth"], rtol=1e-9, atol=1e-14)
+    eng.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# one step from a quantised state: all three precisions x kernel shapes
+# ---------------------------------------------------------------------------------------------
+SHAPES = [
+    (3, 8, 8),        # generic kernel, tiny
+    (2, 9, 13),       # generic kernel, odd non-square
+    (4, 16, 16),      # generic (W/4 < 16)
+    (3, 64, 64),      # tiled TCQ=16 (C1's shape)
+    (2, 50, 64),      # tiled TCQ=16, partial row tile
+    (2, 96, 128),     # tiled TCQ=32
+    (2, 256, 256),    # tiled TCQ=64 (C2's shape)
+    (1, 70, 320),     # tiled TCQ=64, partial column tile + partial row tile
+    (1, 33, 516),     # W % 4 == 0 but not a multiple of the tile width; H = TR + 1
+    (1, 40, 258),     # W % 4 != 0 -> generic
+]
+
+
+@pytest.mark.parametrize("B,H,W", SHAPES)
+@pytest.mark.parametrize("precision", ["f64", "exact", "fast"])
+@pytest.mark.parametrize("L", [0.75, 1.0, 1.31])
+def test_single_step_vs_oracle(amd, B, H, W, precision, L):
+    rng = np.random.RandomState(B * 1000 + H + W)
+    light, dark = _random_quantised(rng, B, H, W)
+    ref = c_oracle.forward(light, dark, L)
+    eng = _engine(amd, B, H, W, 0, precision)
+    eng.upload_state_f32(light.astype(np.float32), dark.astype(np.float32), quantised=True)
+    eng.step(L)
+    gl, gd = eng.download_planes()
+    kl, kd, rl, rd = _k(gl), _k(gd), _k(ref[:, 1]), _k(ref[:, 2])
+    if precision == "fast":
+        dl, dd = np.abs(kl - rl), np.abs(kd - rd)
+        assert dl.max() <= 1 and dd.max() <= 1, "fast mode: more than one quantum off"
+        frac_equal = 1.0 - (np.count_nonzero(dl) + np.count_nonzero(dd)) / (2.0 * dl.size)
+        assert frac_equal >= 0.995, f"fast mode: only {frac_equal:.5f} of cells identical"
+    else:
+        assert np.array_equal(kl, rl) and np.array_equal(kd, rd), f"{precision}: not bit-exact"
+    # fused per-world reductions
+    s = eng.reduce()
+    assert np.array_equal(s["max_k"], np.maximum(kl.max(axis=(1, 2)), kd.max(axis=(1, 2))))
+    assert np.array_equal(s["sum_light_k"], kl.sum(axis=(1, 2)))
+    assert np.array_equal(s["sum_dark_k"], kd.sum(axis=(1, 2)))
+    # previous state is retained un-touched
+    pl, pd = eng.download_planes(1)
+    assert np.array_equal(_k(pl), _k(light)) and np.array_equal(_k(pd), _k(dark))
+    eng.close()
+
+
+def test_exact_mode_uses_float32_path_and_few_fixups(amd):
+    """The exact mode must not silently run everything in float64: only near-tie cells are redone."""
+    rng = np.random.RandomState(5)
+    light, dark = _random_quantised(rng, 4, 256, 256)
+    eng = _engine(amd, 4, 256, 256, 0, "exact")
+    eng.upload_state_f32(light.astype(np.float32), dark.astype(np.float32), quantised=True)
+    eng.step(1.0)
+    n = eng.last_fixup_count()
+    assert "step_tiled" in eng.kernel_info()
+    assert 0 < n < 0.02 * light.size, f"{n} float64 fix-ups for {light.size} cells"
+    eng.close()
+
+
+@pytest.mark.parametrize("over", [
+    dict(albedo_light=0.5, albedo_dark=0.5),          # neutral albedo (notebook sweep)
+    dict(q2=0.0),                                     # set_use_microclimate(False)
+    dict(dt=0.5),
+    dict(dt=2.0, albedo_light=0.8, albedo_dark=0.2),
+    dict(gamma=0.3, temp_optimal=290.0, g=0.004),
+])
+def test_exact_mode_other_constants(amd, over):
+    rng = np.random.RandomState(11)
+    B, H, W = 2, 64, 128
+    light, dark = _random_quantised(rng, B, H, W)
+    for L in (0.8, 1.2):
+        ref = c_oracle.forward(light, dark, L, _oracle_params(**over))
+        eng = _engine(amd, B, H, W, 0, "exact", **over)
+        eng.upload_state_f32(light.astype(np.float32), dark.astype(np.float32), quantised=True)
+        eng.step(L)
+        gl, gd = eng.download_planes()
+        assert np.array_equal(_k(gl), _k(ref[:, 1])) and np.array_equal(_k(gd), _k(ref[:, 2]))
+        eng.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# trajectories
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("precision", ["exact", "f64"])
+def test_c1_trajectory_bit_exact_g2(amd, golden, precision):
+    """BASELINE config 1 (seed 42, B=1, 64x64, no agents, 500 steps) from the reference's own
+    un-quantised float64 initial state: snapshots bit-identical to the reference."""
+    g = golden("G2_c1_trajectory")
+    eng = _engine(amd, 1, 64, 64, 0, precision)
+    eng.upload_state(g["light0"], g["dark0"])
+    L, dL, t = 0.75, 0.75 / 512, 0
+    for snap in (int(s) for s in g["snap_steps"]):
+        L = eng.step_n(snap - t, L, dL, 0.75, 1.5)
+        t = snap
+        gl, gd = eng.download_planes()
+        assert np.array_equal(_k(gl).astype(np.uint16), g[f"light_k_{t}"]), f"light differs at t={t}"
+        assert np.array_equal(_k(gd).astype(np.uint16), g[f"dark_k_{t}"]), f"dark differs at t={t}"
+        grid = eng.download_grid()
+        assert np.array_equal(grid[:, 3:6], g[f"temp3_{t}"])
+        assert np.array_equal(grid[:, 0], g[f"bare_{t}"])
+    assert L == float(g["final_L"])
+    eng.close()
+
+
+def test_c1_trajectory_fast_mode_statistics(amd, golden):
+    """float32-only arithmetic: population curves within 1e-3 absolute of the reference at every
+    step of C1 (cell-wise long-horizon equality is not claimed: the quantiser amplifies ties)."""
+    g = golden("G2_c1_trajectory")
+    eng = _engine(amd, 1, 64, 64, 0, "fast")
+    eng.upload_state(g["light0"], g["dark0"])
+    L, dL = 0.75, 0.75 / 512
+    n = 64 * 64
+    worst = 0.0
+    for t in range(500):
+        L = eng.step_n(1, L, dL, 0.75, 1.5)
+        s = eng.reduce()
+        ml, md = s["sum_light_k"][0] / 1000.0 / n, s["sum_dark_k"][0] / 1000.0 / n
+        worst = max(worst, abs(ml - g["mean_light"][t]), abs(md - g["mean_dark"][t]))
+    assert worst < 1e-3, worst
+    eng.close()
+
+
+def test_multiworld_trajectory_vs_c_oracle(amd):
+    """256x256 worlds (C2's grid), tiled exact kernel, 40 steps from a device-generated state."""
+    B, H, W = 3, 256, 256
+    eng = _engine(amd, B, H, W, 0, "exact")
+    eng.init_random(1234)
+    light, dark = eng.download_planes()
+    L, dL = 0.75, 0.75 / 512
+    Lo = c_oracle.step_n(light, dark, L, dL, 40)
+    Lg = eng.step_n(40, L, dL, 0.75, 1.5)
+    gl, gd = eng.download_planes()
+    assert Lo == Lg
+    assert np.array_equal(_k(gl), _k(light)) and np.array_equal(_k(gd), _k(dark))
+    eng.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# the drop-in class against the reference fixtures
+# ---------------------------------------------------------------------------------------------
+def _g3_actions(g):
+    return [None if f"action_{t}_none" in g.files else g[f"action_{t}"] for t in range(int(g["n_steps"]))]
+
+
+@pytest.mark.parametrize("precision", ["exact", "f64"])
+def test_dropin_agents_g3(amd, golden, precision):
+    g = golden("G3_agents")
+    np.random.seed(7)
+    env = amd.RLDaisyWorld(grid_dimension=8, n_agents=4, precision=precision)
+    env.batch_size = 4
+    env.reset()
+    # same manual edits as the fixture generator (in-place mutation of the public arrays)
+    env.agent_indices[0] = np.array([[2, 4], [1, 3], [6, 6], [0, 0]])
+    env.agent_indices[1] = np.array([[5, 5], [7, 0], [3, 3], [3, 3]])
+    env.agent_states[2, 1, 0] = 0.04
+    env.agent_states[0, :, 0] = 0.3
+    env.L = 1.0
+    assert np.array_equal(env.grid[:, 1], g["light0"]) and np.array_equal(env.grid[:, 2], g["dark0"])
+    assert np.array_equal(env.agent_indices, g["agent_indices0"])
+    for t, a in enumerate(_g3_actions(g)):
+        obs, reward, done, info = env.step(a)
+        assert np.array_equal(env.agent_indices, g["agent_indices"][t]), t
+        assert np.array_equal(env.agent_states, g["agent_states"][t]), t
+        assert np.array_equal(env.grid[:, 1], g["light"][t]), t
+        assert np.array_equal(env.grid[:, 2], g["dark"][t]), t
+        assert np.array_equal(obs, g["obs"][t]), t
+        assert np.array_equal(reward, g["reward"][t]), t
+        assert np.array_equal(done, g["done"][t]) and done.dtype == np.bool_, t
+        assert env.L == g["L_after"][t] and info == {}
+    assert np.array_equal(env.grid, g["grid_final"])
+    env.close()
+
+
+def test_dropin_ctor_rng_order_g9(amd, golden):
+    g = golden("G9_ctor_rng_order")
+    np.random.seed(int(g["seed"]))
+    env = amd.RLDaisyWorld(grid_dimension=16)
+    grid = env.grid
+    assert grid.shape == (32, 7, 16, 16)
+    assert np.array_equal(grid[:, :3], g["ctor_grid"][:, :3])
+    np.testing.assert_allclose(grid[:, 3:6], g["ctor_grid"][:, 3:6], rtol=1e-12)
+    assert np.array_equal(env.agent_indices, g["ctor_agent_indices"])
+    assert env.dL == float(g["ctor_dL"]) and env.L == float(g["ctor_L"])
+    env.batch_size = 5
+    env.n_agents = 3
+    env.albedo_light = 0.7
+    env.min_L = 0.8
+    env.ramp_period = 100
+    obs = env.reset()
+    assert np.array_equal(env.grid[:, :3], g["reset_grid"][:, :3])
+    np.testing.assert_allclose(env.grid[:, 3:6], g["reset_grid"][:, 3:6], rtol=1e-12)
+    assert np.array_equal(env.agent_indices, g["reset_agent_indices"])
+    assert np.array_equal(env.agent_states, g["reset_agent_states"])
+    np.testing.assert_allclose(obs, g["reset_obs"], rtol=1e-12, atol=0)
+    assert env.dL == float(g["reset_dL"]) and env.L == float(g["reset_L"])
+    obs, reward, done, _ = env.step(np.random.randint(9, size=(5, 3, 1)))
+    assert np.array_equal(obs, g["step_obs"])
+    assert np.array_equal(reward, g["step_reward"]) and np.array_equal(done, g["step_done"])
+    assert np.array_equal(env.grid, g["step_grid"])
+    assert env.L == float(g["step_L"])
+    cfg = env.make_config()
+    assert sorted(cfg.keys()) == list(g["config_keys"])
+    assert np.allclose([float(cfg[k]) for k in sorted(cfg)], g["config_vals"], rtol=0, atol=0)
+    env.close()
+
+
+def test_dropin_no_agents_g7(amd, golden):
+    g = golden("G7_no_agents")
+    np.random.seed(21)
+    env = amd.RLDaisyWorld(grid_dimension=12, n_agents=0)
+    env.batch_size = 3
+    obs0 = env.reset()
+    assert tuple(obs0.shape) == tuple(g["obs0_shape"])
+    assert np.array_equal(env.grid[:, :3], g["grid0"][:, :3])
+    for t in range(6):
+        obs, reward, done, info = env.step()
+        assert reward.dtype == np.bool_ and reward.shape == (3, 2)
+        assert np.array_equal(reward, g["reward"][t]) and np.array_equal(done, g["done"][t])
+        assert np.array_equal(env.grid, g["grids"][t])
+    assert tuple(obs.shape) == (3, 0, 7, 3, 3)
+    assert env.L == float(g["L_final"]) and env.step_count == int(g["step_count"])
+    env.grid[1, 1:3] = 0.0          # in-place edit of the public array, as the fixture generator did
+    obs, reward, done, info = env.step()
+    assert np.array_equal(reward, g["dead_reward"]) and np.array_equal(done, g["dead_done"])
+    env.close()
+
+
+def test_reference_smoke_tests_on_dropin(amd):
+    """The reference's own tests (tests/daisy/test_daisy_world_rl.py:14-68), run on the drop-in."""
+    env = amd.RLDaisyWorld()
+    a = env.grid
+    b = env.forward(a)
+    for ii in range(9):
+        action = np.array([[[ii]]])
+        obs, reward, done, info = env.step(action)
+    assert not done.mean()
+    assert type(info) == dict
+    assert 0.0 <= reward.mean()
+    assert a.shape == b.shape
+    assert obs.shape[1] == env.n_agents and obs.shape[0] == env.batch_size
+    env = amd.RLDaisyWorld()
+    for ch in (3, 4, 5):
+        assert 0 < env.grid[:, ch].mean()
+    env.reset()
+    for ch in (3, 4, 5):
+        assert 0 < env.grid[:, ch].mean()
+    obs, reward, done, info = env.step()
+    for ch in (3, 4, 5):
+        assert 0 < env.grid[:, ch].mean() and 0 < obs[:, :, ch].mean()
+    action = np.random.randint(9, size=(env.batch_size, env.n_agents, 1))
+    obs, reward, done, info = env.step(action)
+    for ch in (3, 4, 5):
+        assert 0 < env.grid[:, ch].mean() and 0 < obs[:, :, ch].mean()
+    env.close()
+
+
+@pytest.mark.parametrize("agent_status,daisy_status", [
+    ("greedy", "light_and_dark"), ("antigreedy", "light_and_dark"), ("random", "neutral_albedo"),
+    ("half_random", "light_and_dark"), ("no", "light_and_dark")])
+def test_dropin_lifespans_g5(amd, golden, agent_status, daisy_status):
+    """The README's lifespan sweep protocol (dim 8, N=4, seed 13) on B=100 worlds: per-world
+    biosphere and agent lifespans identical to the reference's."""
+    g = golden("G5_lifespans")
+    B, seed = int(g["B"]), int(g["seed"])
+    np.random.seed(seed)
+    env = amd.RLDaisyWorld(grid_dimension=8)
+    env.batch_size = B
+    if daisy_status == "neutral_albedo":
+        env.albedo_dark = env.albedo_light = env.albedo_bare
+    agent = {"greedy": amd.Greedy(epsilon=0.0), "antigreedy": amd.Greedy(epsilon=0.0, greedy=False),
+             "random": amd.Greedy(epsilon=1.0), "half_random": amd.Greedy(epsilon=0.5), "no": None}[agent_status]
+    env.reset()
+    done_at, agents_done_at = O.simulate_lifespan(env, agent)   # the notebook's harness, any env
+    key = f"{agent_status}_{daisy_status}"
+    assert np.array_equal(done_at, g[key + "_done_at"])
+    assert np.array_equal(agents_done_at, g[key + "_agents_done_at"])
+    env.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# device-side pieces
+# ---------------------------------------------------------------------------------------------
+def test_device_greedy_policy_matches_host_policy(amd):
+    np.random.seed(3)
+    env = amd.RLDaisyWorld(grid_dimension=8, n_agents=4)
+    env.batch_size = 64
+    obs = env.reset()
+    for _ in range(5):
+        obs, *_ = env.step(np.random.randint(9, size=(64, 4, 1)))
+    for argmin in (False, True):
+        host = amd.Greedy(epsilon=0.0, greedy=not argmin)(obs)[..., 0]
+        env._engine.policy_greedy(argmin=argmin)
+        dev = env._engine.download_actions()
+        assert np.array_equal(host, dev)
+    env.close()
+
+
+def test_init_random_distribution_and_shard_invariance(amd):
+    B, H, W, N = 6, 64, 64, 3
+    full = _engine(amd, B, H, W, N, "exact")
+    full.init_random(99)
+    fl, fd = full.download_planes()
+    fi, fs = full.download_agents()
+    # same worlds when the ensemble is sharded: world_offset keys the RNG
+    for off, nb in ((0, 2), (2, 4)):
+        sh = _engine(amd, nb, H, W, N, "exact", world_offset=off)
+        sh.init_random(99)
+        sl, sd = sh.download_planes()
+        si, ss = sh.download_agents()
+        assert np.array_equal(sl, fl[off:off + nb]) and np.array_equal(sd, fd[off:off + nb])
+        assert np.array_equal(si, fi[off:off + nb]) and np.array_equal(ss, fs[off:off + nb])
+        sh.close()
+    # distribution of ref initialize_grid :299-302: P(cover>0)=0.33, cover = 0.2*U
+    for plane in (fl, fd):
+        frac = (plane > 0).mean()
+        assert abs(frac - 0.33) < 0.01
+        vals = plane[plane > 0]
+        assert vals.max() <= 0.2 and abs(vals.mean() - 0.1) < 0.003
+    assert not np.array_equal(fl, fd)
+    assert fi.min() >= 0 and fi[..., 0].max() < H and fi[..., 1].max() < W and np.all(fs == 1.0)
+    full.close()
+
+
+def test_lifespan_accumulators(amd):
+    np.random.seed(13)
+    env = amd.RLDaisyWorld(grid_dimension=8, n_agents=4)
+    env.batch_size = 16
+    env.min_L, env.max_L, env.ramp_period = 1.3, 1.6, 16      # hot: worlds die quickly
+    obs = env.reset()
+    eng = env._engine
+    eng.lifespan_reset()
+    done_at = np.zeros(16, dtype=int)
+    agents_done_at = np.zeros((16, 4, 1), dtype=int)
+    for _ in range(40):
+        obs, reward, done, _ = env.step(np.random.randint(9, size=(16, 4, 1)))
+        eng.lifespan_accumulate(5)
+        done_at += (1 - 1 * (env.grid[:, 1:3].max(axis=(1, 2, 3)) <= 0.005))
+        agents_done_at += (1 - 1 * done)
+    d, a, alive = eng.lifespan_download()
+    assert np.array_equal(d, done_at) and np.array_equal(a, agents_done_at)
+    assert alive == int((env.grid[:, 1:3].max(axis=(1, 2, 3)) > 0.005).sum())
+    env.close()

@@ -1,0 +1,132 @@
+"""ctypes binding of include/daisyworld_hip.h (libdaisyworld_hip.so).
+
+There is deliberately no fallback: if the shared library is missing, or no gfx950 device is
+usable, the calls raise.  Build the library with ``python -m therldaisyworld_amd.build`` (or
+``__graft_entry__.build()``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdaisyworld_hip.so")
+
+DW_ABI_VERSION = 1
+DW_OK, DW_EINVAL, DW_ENODEVICE, DW_ENOMEM, DW_EHIP, DW_ESTATE = 0, -1, -2, -3, -4, -5
+PRECISION = {"exact": 0, "fast": 1, "f64": 2}
+STATE_CURRENT, STATE_PREVIOUS = 0, 1
+POLICY_ARGMAX, POLICY_ARGMIN = 0, 1
+
+
+class DaisyHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libdaisyworld_hip error {code}: {msg}")
+        self.code = code
+
+
+class DwParams(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32), ("batch", C.c_int32), ("height", C.c_int32), ("width", C.c_int32),
+        ("n_agents", C.c_int32), ("device", C.c_int32), ("precision", C.c_int32), ("obs_mask", C.c_int32),
+        ("collision_mode", C.c_int32), ("reserved0", C.c_int32), ("world_offset", C.c_int64),
+    ] + [(n, C.c_double) for n in (
+        "p", "g", "S", "sigma", "gamma", "q", "q2", "dt",
+        "albedo_bare", "albedo_light", "albedo_dark", "temp_optimal",
+        "agent_gamma", "food_chain_penalty",
+        "initial_al", "initial_ad", "light_proportion", "dark_proportion")]
+
+
+class DwWorldStats(C.Structure):
+    _fields_ = [("max_k", C.c_uint32), ("reserved", C.c_uint32), ("sum_light_k", C.c_uint64),
+                ("sum_dark_k", C.c_uint64)]
+
+
+STATS_DTYPE = np.dtype([("max_k", "<u4"), ("reserved", "<u4"), ("sum_light_k", "<u8"), ("sum_dark_k", "<u8")])
+
+_vp, _i32, _i64, _u32, _u64, _dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_double
+_pd, _pi, _pf, _pu8 = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_uint8)
+
+# name -> (restype, argtypes); every symbol include/daisyworld_hip.h declares
+SIGNATURES = {
+    "dw_default_params": (C.c_int, [C.POINTER(DwParams), _i32, _i32, _i32, _i32]),
+    "dw_create": (C.c_int, [C.POINTER(DwParams), C.POINTER(_vp)]),
+    "dw_destroy": (C.c_int, [_vp]),
+    "dw_set_params": (C.c_int, [_vp, C.POINTER(DwParams)]),
+    "dw_get_params": (C.c_int, [_vp, C.POINTER(DwParams)]),
+    "dw_last_error": (C.c_char_p, []),
+    "dw_abi_version": (C.c_int, []),
+    "dw_upload_state_f64": (C.c_int, [_vp, _pd, _pd]),
+    "dw_upload_state_f32": (C.c_int, [_vp, _pf, _pf, C.c_int]),
+    "dw_upload_agents": (C.c_int, [_vp, _pi, _pd]),
+    "dw_download_agents": (C.c_int, [_vp, _pi, _pd]),
+    "dw_init_random": (C.c_int, [_vp, _u64]),
+    "dw_download_planes": (C.c_int, [_vp, C.c_int, _pd, _pd]),
+    "dw_download_grid": (C.c_int, [_vp, _dbl, _pd]),
+    "dw_download_caches": (C.c_int, [_vp, _dbl, _pd, _pd, _pd, _pd]),
+    "dw_step": (C.c_int, [_vp, _pi, _i32, _i32, _dbl]),
+    "dw_step_device_actions": (C.c_int, [_vp, _dbl]),
+    "dw_upload_actions": (C.c_int, [_vp, _pi]),
+    "dw_download_actions": (C.c_int, [_vp, _pi]),
+    "dw_step_n": (C.c_int, [_vp, _i32, _pd, _dbl, _dbl, _dbl, C.c_int]),
+    "dw_update_agents": (C.c_int, [_vp, _pi, _i32, _i32]),
+    "dw_forward_f64": (C.c_int, [_vp, _pd, _pd, _dbl, _pd, _pd, _pd, _pd, _pd]),
+    "dw_get_obs": (C.c_int, [_vp, _dbl, _pd]),
+    "dw_get_reward_done": (C.c_int, [_vp, _pd, _pu8]),
+    "dw_reduce": (C.c_int, [_vp, C.POINTER(DwWorldStats)]),
+    "dw_policy_greedy": (C.c_int, [_vp, C.c_int]),
+    "dw_lifespan_reset": (C.c_int, [_vp]),
+    "dw_lifespan_accumulate": (C.c_int, [_vp, _u32]),
+    "dw_lifespan_download": (C.c_int, [_vp, _pi, _pi, _pi]),
+    "dw_set_stream": (C.c_int, [_vp, _vp]),
+    "dw_sync": (C.c_int, [_vp]),
+    "dw_timer_start": (C.c_int, [_vp]),
+    "dw_timer_stop": (C.c_int, [_vp, C.POINTER(C.c_float)]),
+    "dw_device_planes": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), C.POINTER(_vp)]),
+    "dw_kernel_info": (C.c_int, [_vp, C.c_char_p, C.c_size_t]),
+    "dw_last_fixup_count": (C.c_int, [_vp, C.POINTER(_u64)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library and declare every prototype.  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build the HIP extension first "
+                "(python -m therldaisyworld_amd.build); there is no CPU fallback")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)     # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        if lib.dw_abi_version() != DW_ABI_VERSION:
+            raise ImportError("libdaisyworld_hip.so ABI version mismatch; rebuild it")
+        _lib = lib
+    return _lib
+
+
+def check(rc):
+    if rc != DW_OK:
+        raise DaisyHipError(rc, load().dw_last_error().decode("utf-8", "replace"))
+
+
+def ptr_d(a):
+    return None if a is None else a.ctypes.data_as(_pd)
+
+
+def ptr_i(a):
+    return None if a is None else a.ctypes.data_as(_pi)
+
+
+def ptr_f(a):
+    return None if a is None else a.ctypes.data_as(_pf)
+
+
+def ptr_u8(a):
+    return None if a is None else a.ctypes.data_as(_pu8)

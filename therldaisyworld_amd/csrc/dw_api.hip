@@ -1,0 +1,953 @@
+// dw_api.hip — C ABI (include/daisyworld_hip.h) over the gfx950 kernels in dw_kernels.hpp.
+//
+// Host-side responsibilities: device state (ping-pong per-mille planes, agents, reductions),
+// per-step derivation of the float32 coefficient set from the float64 constants and the current
+// luminosity, kernel selection by grid shape, and the bookkeeping of which retained state is
+// quantised / has an exact float64 copy.  No CPU compute path exists here.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "../../include/daisyworld_hip.h"
+#include "dw_kernels.hpp"
+
+using namespace dw;
+
+// ------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIPCHK(expr)                                                                           \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(e_ == hipErrorOutOfMemory ? DW_ENOMEM : DW_EHIP, "%s failed: %s (%s:%d)", \
+                        #expr, hipGetErrorString(e_), __FILE__, __LINE__);                      \
+    } while (0)
+
+#define NEED(cond, code, ...)                      \
+    do {                                           \
+        if (!(cond)) return fail(code, __VA_ARGS__); \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// handle
+// ------------------------------------------------------------------------------------------------
+enum F64Owner { F64_NONE = 0, F64_CUR = 1, F64_PREV = 2 };
+
+struct dw_handle {
+    dw_params prm;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    size_t cells = 0;                 // B*H*W
+    float* L32[2] = {nullptr, nullptr};
+    float* D32[2] = {nullptr, nullptr};
+    int cur = 0;
+    double* L64 = nullptr;            // exact natural-unit copy of an un-quantised upload
+    double* D64 = nullptr;
+    F64Owner f64 = F64_NONE;
+    bool have_state = false;
+    bool cur_quantised = false;
+    bool stepped = false;             // prev/cur form a forward() pair
+    double L_last = 0.0;              // luminosity of the last forward()
+    int* idx = nullptr;               // [B][N][2]
+    double* st = nullptr;             // [B][N]
+    int* action = nullptr;            // [B][N]
+    int* action_tmp = nullptr;        // staging for host-supplied (possibly sub-shaped) actions
+    bool have_agents = false;
+    StatsDev* stats = nullptr;        // [B]
+    unsigned long long* fixups = nullptr;
+    int* done_at = nullptr;           // [B]
+    int* agents_done_at = nullptr;    // [B][N]
+    int* n_alive = nullptr;
+    double* scratch = nullptr;        // device staging for float64 downloads / uploads
+    size_t scratch_bytes = 0;
+    double* reward_d = nullptr;       // [B][N]
+    unsigned char* done_d = nullptr;  // [B][N]
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // kernel selection
+    int tcq = 0, rpt = 0;             // 0 => generic
+    Geom geom{};
+    size_t tile_lds = 0;
+};
+
+static int ensure_scratch(dw_handle* h, size_t bytes) {
+    if (h->scratch_bytes >= bytes) return DW_OK;
+    if (h->scratch) HIPCHK(hipFree(h->scratch));
+    h->scratch = nullptr;
+    h->scratch_bytes = 0;
+    HIPCHK(hipMalloc(&h->scratch, bytes));
+    h->scratch_bytes = bytes;
+    return DW_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// constants: float64 set and the per-step float32 set
+// ------------------------------------------------------------------------------------------------
+static PhysF64 make_f64(const dw_params& p, double L) {
+    PhysF64 P;
+    P.p = p.p; P.g = p.g; P.S = p.S; P.sigma = p.sigma; P.gamma = p.gamma; P.q = p.q; P.q2 = p.q2;
+    P.dt = p.dt; P.ab = p.albedo_bare; P.al = p.albedo_light; P.ad = p.albedo_dark;
+    P.To = p.temp_optimal; P.L = L;
+    // ref daisy_world_rl.py:270-273: ones*e^-1, centre 1, corners e^-2, normalised
+    const double e1 = std::exp(-1.0), e2 = std::exp(-2.0);
+    const double s = 1.0 + 4.0 * e1 + 4.0 * e2;
+    P.w0 = 1.0 / s; P.w1 = e1 / s; P.w2 = e2 / s;
+    return P;
+}
+
+static void split_hi_lo(double v, double scale, float* hi, float* lo) {
+    const double h = std::nearbyint(v * scale) / scale;
+    *hi = (float)h;
+    *lo = (float)(v - h);
+}
+
+// Derivation of the fused float32 coefficients (see dw_physics.hpp, PhysF32) and of the exact-mode
+// tie bound (DESIGN.md §"Exact mode").  All in float64, rounded once.
+static PhysF32 derive_f32(const dw_params& p, double L) {
+    const double To4 = std::pow(p.temp_optimal, 4);
+    const double K = p.S * L / p.sigma;
+    const double dal = p.albedo_light - p.albedo_bare, dad = p.albedo_dark - p.albedo_bare;
+    const double a1 = (p.q - K) * dal / (8000.0 * To4);
+    const double a2 = (p.q - K) * dad / (8000.0 * To4);
+    const double a3 = (-p.q + p.q2) * dal / (1000.0 * To4);
+    const double a4 = (-p.q + p.q2) * dad / (1000.0 * To4);
+    const double e0 = K * (1.0 - p.albedo_bare * p.p) / To4 - 1.0;
+    const double c0l = e0 + p.q2 * (p.albedo_bare * p.p - p.albedo_light) / To4;
+    const double c0d = e0 + p.q2 * (p.albedo_bare * p.p - p.albedo_dark) / To4;
+    // hi parts are multiples of 2^-hb with hb chosen so that every partial sum of the hi chain
+    // (|.| <= maxsum) stays below 2^(24-hb): exactly representable in float32 for integer inputs.
+    const double kmax = 1000.0 * p.p;
+    const double maxsum = std::fabs(a1) * 8 * kmax + std::fabs(a2) * 8 * kmax + std::fabs(a3) * kmax +
+                          std::fabs(a4) * kmax + std::fmax(std::fabs(c0l), std::fabs(c0d));
+    int hb = 23 - (int)std::ceil(std::log2(std::fmax(maxsum, 1e-30)));
+    if (hb > 40) hb = 40;
+    if (hb < 0) hb = 0;
+    const double scale = std::ldexp(1.0, hb);
+    PhysF32 P;
+    split_hi_lo(a1, scale, &P.a1h, &P.a1l);
+    split_hi_lo(a2, scale, &P.a2h, &P.a2l);
+    split_hi_lo(a3, scale, &P.a3h, &P.a3l);
+    split_hi_lo(a4, scale, &P.a4h, &P.a4l);
+    split_hi_lo(c0l, scale, &P.c0lh, &P.c0ll);
+    split_hi_lo(c0d, scale, &P.c0dh, &P.c0dl);
+    P.cbeta = (float)(p.g * p.temp_optimal * p.temp_optimal);
+    const PhysF64 P64 = make_f64(p, L);
+    P.w0 = (float)P64.w0; P.w1 = (float)P64.w1; P.w2 = (float)P64.w2;
+    P.p = (float)p.p; P.gamma = (float)p.gamma; P.dt = (float)p.dt;
+    // ---- tie bound (per-mille), DESIGN.md "Exact mode":
+    //   |gq32 - gq64| <= A0 + eA*|gq| + |dt*K| * (eK0 + eK1*om),   om = 1 - beta >= 0
+    const double u = std::ldexp(1.0, -24);
+    // absolute error of e: only the lo chain rounds (hi chain exact); lo coefficients <= 2^-(hb+1)
+    const double lo_mag = std::ldexp(1.0, -(hb + 1)) * 18.0 * kmax + std::ldexp(1.0, -(hb + 1));
+    const double de_abs = 6.0 * u * lo_mag + 1e-9;
+    // largest |(T-To)/To| over admissible states (signs of the coefficients respected)
+    const double pos = std::fmax(std::fmax(a1, a2), 0.0) * 8 * kmax + std::fmax(std::fmax(a3, a4), 0.0) * kmax;
+    const double neg = std::fmin(std::fmin(a1, a2), 0.0) * 8 * kmax + std::fmin(std::fmin(a3, a4), 0.0) * kmax;
+    const double emax = std::fmax(c0l, c0d) + pos, emin = std::fmin(c0l, c0d) + neg;
+    const double dabs = std::fmax(std::fabs(std::pow(std::fmax(1.0 + emax, 1e-6), 0.25) - 1.0),
+                                  std::fabs(std::pow(std::fmax(1.0 + emin, 1e-6), 0.25) - 1.0));
+    const double cb = p.g * p.temp_optimal * p.temp_optimal;
+    const double safety = 2.0;
+    const double A0 = safety * (0.25 * kmax * std::fabs(p.dt) * cb * dabs * de_abs + 4.0 * u * kmax * 0.25 + 2e-5);
+    P.tie_lo = (float)(0.5 - A0);
+    P.eA = (float)(safety * 9.0 * u);
+    P.eK0 = (float)(safety * 5.0 * u);
+    P.eK1 = (float)(safety * 28.0 * u);
+    return P;
+}
+
+// ------------------------------------------------------------------------------------------------
+// kernel selection
+// ------------------------------------------------------------------------------------------------
+static void select_kernel(dw_handle* h) {
+    const dw_params& p = h->prm;
+    h->tcq = 0;
+    h->rpt = 0;
+    if (p.precision == DW_PRECISION_F64) return;
+    if (p.width % 4 != 0) return;
+    const int Wq = p.width / 4;
+    if (Wq >= 64) { h->tcq = 64; h->rpt = 8; }
+    else if (Wq >= 32) { h->tcq = 32; h->rpt = 4; }
+    else if (Wq >= 16) { h->tcq = 16; h->rpt = 2; }
+    else return;   // narrow grids: generic kernel
+    const int TR = (256 / h->tcq) * h->rpt;
+    Geom& g = h->geom;
+    g.B = p.batch; g.H = p.height; g.W = p.width; g.Wq = Wq;
+    g.tiles_r = (p.height + TR - 1) / TR;
+    g.tiles_c = (Wq + h->tcq - 1) / h->tcq;
+    g.ntiles = p.batch * g.tiles_r * g.tiles_c;
+    g.chunk = (g.ntiles + 7) / 8;
+    h->tile_lds = (size_t)2 * (TR + 2) * (h->tcq + 2) * 4 * sizeof(float);
+}
+
+template <int TCQ, int RPT, bool EXACT>
+static int launch_tiled(dw_handle* h, const float* iL, const float* iD, float* oL, float* oD,
+                        const PhysF32& P, const PhysF64& P64) {
+    auto kern = step_tiled<TCQ, RPT, EXACT>;
+    static bool attr_set = false;   // per instantiation
+    if (!attr_set) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)(TileCfg<TCQ, RPT>::LDS_BYTES)));
+        attr_set = true;
+    }
+    const unsigned grid = (unsigned)h->geom.chunk * 8u;
+    constexpr size_t lds_bytes = TileCfg<TCQ, RPT>::LDS_BYTES;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, h->stream, iL, iD, oL, oD, h->geom, P, P64,
+                       h->stats, h->fixups);
+    HIPCHK(hipGetLastError());
+    return DW_OK;
+}
+
+// forward(): cur -> other buffer, swap.  Assumes agents were already updated.
+static int launch_forward(dw_handle* h, double L) {
+    const dw_params& p = h->prm;
+    NEED(h->have_state, DW_ESTATE, "no state uploaded (call dw_upload_state_* or dw_init_random)");
+    const int in = h->cur, out = 1 - h->cur;
+    const PhysF32 P = derive_f32(p, L);
+    const PhysF64 P64 = make_f64(p, L);
+    HIPCHK(hipMemsetAsync(h->stats, 0, sizeof(StatsDev) * p.batch, h->stream));
+    HIPCHK(hipMemsetAsync(h->fixups, 0, sizeof(unsigned long long), h->stream));
+    const dim3 ggrid((unsigned)((p.height * p.width + 255) / 256), (unsigned)p.batch);
+    int prec = p.precision;
+    if (prec == DW_PRECISION_EXACT && !h->cur_quantised) prec = DW_PRECISION_F64;  // first step
+    if (prec == DW_PRECISION_F64) {
+        if (h->f64 == F64_CUR)
+            hipLaunchKernelGGL((step_generic<double, 2>), ggrid, dim3(256), 0, h->stream, h->L64, h->D64,
+                               h->L32[out], h->D32[out], p.height, p.width, P, P64, h->stats, h->fixups);
+        else
+            hipLaunchKernelGGL((step_generic<float, 2>), ggrid, dim3(256), 0, h->stream, h->L32[in],
+                               h->D32[in], h->L32[out], h->D32[out], p.height, p.width, P, P64, h->stats,
+                               h->fixups);
+        HIPCHK(hipGetLastError());
+    } else if (h->tcq == 0) {
+        if (prec == DW_PRECISION_EXACT)
+            hipLaunchKernelGGL((step_generic<float, 0>), ggrid, dim3(256), 0, h->stream, h->L32[in],
+                               h->D32[in], h->L32[out], h->D32[out], p.height, p.width, P, P64, h->stats,
+                               h->fixups);
+        else
+            hipLaunchKernelGGL((step_generic<float, 1>), ggrid, dim3(256), 0, h->stream, h->L32[in],
+                               h->D32[in], h->L32[out], h->D32[out], p.height, p.width, P, P64, h->stats,
+                               h->fixups);
+        HIPCHK(hipGetLastError());
+    } else {
+        const bool ex = prec == DW_PRECISION_EXACT;
+        int rc;
+#define DW_TILED(T, R)                                                                              \
+    rc = ex ? launch_tiled<T, R, true>(h, h->L32[in], h->D32[in], h->L32[out], h->D32[out], P, P64)  \
+            : launch_tiled<T, R, false>(h, h->L32[in], h->D32[in], h->L32[out], h->D32[out], P, P64)
+        if (h->tcq == 64) { DW_TILED(64, 8); }
+        else if (h->tcq == 32) { DW_TILED(32, 4); }
+        else { DW_TILED(16, 2); }
+#undef DW_TILED
+        if (rc != DW_OK) return rc;
+    }
+    h->cur = out;
+    h->f64 = (h->f64 == F64_CUR) ? F64_PREV : F64_NONE;
+    h->cur_quantised = true;
+    h->stepped = true;
+    h->L_last = L;
+    return DW_OK;
+}
+
+static int launch_agents(dw_handle* h, const int* d_action, int act_b, int act_n) {
+    const dw_params& p = h->prm;
+    if (p.n_agents == 0) return DW_OK;
+    NEED(h->have_state, DW_ESTATE, "no state uploaded");
+    NEED(h->have_agents, DW_ESTATE, "no agents uploaded (call dw_upload_agents or dw_init_random)");
+    NEED(p.collision_mode == 0, DW_EINVAL, "collision_mode=1 is not implemented on the device");
+    const int blocks = (p.batch + 63) / 64;
+    hipLaunchKernelGGL(agents_update, dim3(blocks), dim3(64), 0, h->stream, h->L32[h->cur],
+                       h->D32[h->cur], h->f64 == F64_CUR ? h->L64 : nullptr,
+                       h->f64 == F64_CUR ? h->D64 : nullptr, h->idx, h->st, d_action, act_b, act_n,
+                       p.batch, p.n_agents, p.height, p.width, p.agent_gamma);
+    HIPCHK(hipGetLastError());
+    return DW_OK;
+}
+
+static int stage_host_actions(dw_handle* h, const int32_t* action, int b, int n) {
+    const dw_params& p = h->prm;
+    NEED(b >= 0 && n >= 0 && b <= p.batch && n <= p.n_agents, DW_EINVAL,
+         "action block %dx%d exceeds (B,N)=(%d,%d)", b, n, p.batch, p.n_agents);
+    if ((size_t)b * n)
+        HIPCHK(hipMemcpyAsync(h->action_tmp, action, sizeof(int) * (size_t)b * n, hipMemcpyHostToDevice,
+                              h->stream));
+    return DW_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* dw_last_error(void) { return g_err; }
+int dw_abi_version(void) { return DW_ABI_VERSION; }
+
+int dw_default_params(dw_params* p, int32_t batch, int32_t height, int32_t width, int32_t n_agents) {
+    NEED(p, DW_EINVAL, "null params");
+    std::memset(p, 0, sizeof(*p));
+    p->abi_version = DW_ABI_VERSION;
+    p->batch = batch; p->height = height; p->width = width; p->n_agents = n_agents;
+    p->device = 0; p->precision = DW_PRECISION_EXACT; p->obs_mask = 0x0BA; p->collision_mode = 0;
+    p->world_offset = 0;
+    p->p = 1.0; p->g = 0.003265; p->S = 1000.0; p->sigma = 5.67e-8; p->gamma = 0.25;
+    p->q = 0.2 * p->S / p->sigma; p->q2 = p->q / 8.0; p->dt = 1.0;
+    p->albedo_bare = 0.5; p->albedo_light = 0.75; p->albedo_dark = 0.25; p->temp_optimal = 295.5;
+    p->agent_gamma = 0.05; p->food_chain_penalty = 0.5;
+    p->initial_al = 0.2; p->initial_ad = 0.2; p->light_proportion = 0.33; p->dark_proportion = 0.33;
+    return DW_OK;
+}
+
+static int check_params(const dw_params* p) {
+    NEED(p, DW_EINVAL, "null params");
+    NEED(p->abi_version == DW_ABI_VERSION, DW_EINVAL, "ABI version %d != %d", p->abi_version, DW_ABI_VERSION);
+    NEED(p->batch >= 1 && p->height >= 3 && p->width >= 3, DW_EINVAL,
+         "need batch>=1 and grid >= 3x3 (got B=%d H=%d W=%d)", p->batch, p->height, p->width);
+    NEED(p->height <= 65535 && p->width <= 65532, DW_EINVAL, "grid dimension too large");
+    NEED(p->n_agents >= 0, DW_EINVAL, "n_agents < 0");
+    NEED(p->precision >= 0 && p->precision <= 2, DW_EINVAL, "bad precision %d", p->precision);
+    NEED((double)p->batch * p->height * p->width < 9.0e18, DW_EINVAL, "too many cells");
+    return DW_OK;
+}
+
+int dw_create(const dw_params* p, dw_handle** out) {
+    NEED(out, DW_EINVAL, "null out");
+    *out = nullptr;
+    int rc = check_params(p);
+    if (rc) return rc;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(DW_ENODEVICE, "no HIP device available (this library has no CPU fallback)");
+    NEED(p->device >= 0 && p->device < ndev, DW_ENODEVICE, "device %d out of range (%d devices)", p->device, ndev);
+    HIPCHK(hipSetDevice(p->device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, p->device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(DW_ENODEVICE, "device %d is %s; this library is built for gfx950 only", p->device,
+                    prop.gcnArchName);
+    dw_handle* h = new (std::nothrow) dw_handle();
+    NEED(h, DW_ENOMEM, "host allocation failed");
+    h->prm = *p;
+    h->cells = (size_t)p->batch * p->height * p->width;
+    auto cleanup = [&](int code) { dw_destroy(h); return code; };
+#define TRY(expr)                                                                                  \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return cleanup(fail(e_ == hipErrorOutOfMemory ? DW_ENOMEM : DW_EHIP, "%s failed: %s", #expr, \
+                                hipGetErrorString(e_)));                                           \
+    } while (0)
+    TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    h->own_stream = true;
+    for (int i = 0; i < 2; ++i) {
+        TRY(hipMalloc(&h->L32[i], sizeof(float) * h->cells));
+        TRY(hipMalloc(&h->D32[i], sizeof(float) * h->cells));
+    }
+    const size_t bn = (size_t)p->batch * (p->n_agents > 0 ? p->n_agents : 1);
+    TRY(hipMalloc(&h->idx, sizeof(int) * bn * 2));
+    TRY(hipMalloc(&h->st, sizeof(double) * bn));
+    TRY(hipMalloc(&h->action, sizeof(int) * bn));
+    TRY(hipMalloc(&h->action_tmp, sizeof(int) * bn));
+    TRY(hipMalloc(&h->reward_d, sizeof(double) * bn));
+    TRY(hipMalloc(&h->done_d, bn));
+    TRY(hipMalloc(&h->agents_done_at, sizeof(int) * bn));
+    TRY(hipMalloc(&h->done_at, sizeof(int) * p->batch));
+    TRY(hipMalloc(&h->n_alive, sizeof(int)));
+    TRY(hipMalloc(&h->stats, sizeof(StatsDev) * p->batch));
+    TRY(hipMalloc(&h->fixups, sizeof(unsigned long long)));
+    TRY(hipMemsetAsync(h->action, 0, sizeof(int) * bn, h->stream));
+    TRY(hipMemsetAsync(h->stats, 0, sizeof(StatsDev) * p->batch, h->stream));
+    TRY(hipMemsetAsync(h->fixups, 0, sizeof(unsigned long long), h->stream));
+    TRY(hipMemsetAsync(h->done_at, 0, sizeof(int) * p->batch, h->stream));
+    TRY(hipMemsetAsync(h->agents_done_at, 0, sizeof(int) * bn, h->stream));
+    TRY(hipMemsetAsync(h->n_alive, 0, sizeof(int), h->stream));
+    TRY(hipEventCreate(&h->ev0));
+    TRY(hipEventCreate(&h->ev1));
+#undef TRY
+    select_kernel(h);
+    *out = h;
+    return DW_OK;
+}
+
+int dw_destroy(dw_handle* h) {
+    if (!h) return DW_OK;
+    (void)hipSetDevice(h->prm.device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (int i = 0; i < 2; ++i) { (void)hipFree(h->L32[i]); (void)hipFree(h->D32[i]); }
+    (void)hipFree(h->L64); (void)hipFree(h->D64);
+    (void)hipFree(h->idx); (void)hipFree(h->st); (void)hipFree(h->action); (void)hipFree(h->action_tmp);
+    (void)hipFree(h->reward_d); (void)hipFree(h->done_d);
+    (void)hipFree(h->agents_done_at); (void)hipFree(h->done_at); (void)hipFree(h->n_alive);
+    (void)hipFree(h->stats); (void)hipFree(h->fixups); (void)hipFree(h->scratch);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return DW_OK;
+}
+
+int dw_set_params(dw_handle* h, const dw_params* p) {
+    NEED(h, DW_EINVAL, "null handle");
+    int rc = check_params(p);
+    if (rc) return rc;
+    const dw_params& o = h->prm;
+    NEED(p->batch == o.batch && p->height == o.height && p->width == o.width && p->n_agents == o.n_agents &&
+             p->device == o.device,
+         DW_EINVAL, "dw_set_params cannot change shape or device; create a new handle");
+    h->prm = *p;
+    select_kernel(h);
+    return DW_OK;
+}
+
+int dw_get_params(const dw_handle* h, dw_params* out) {
+    NEED(h && out, DW_EINVAL, "null argument");
+    *out = h->prm;
+    return DW_OK;
+}
+
+// ---- state in / out ---------------------------------------------------------------------------
+
+static int refresh_stats_f32(dw_handle* h) {
+    const dw_params& p = h->prm;
+    HIPCHK(hipMemsetAsync(h->stats, 0, sizeof(StatsDev) * p.batch, h->stream));
+    const dim3 g((unsigned)((p.height * p.width + 255) / 256), (unsigned)p.batch);
+    hipLaunchKernelGGL((stats_only<float>), g, dim3(256), 0, h->stream, h->L32[h->cur], h->D32[h->cur],
+                       p.height, p.width, h->stats);
+    HIPCHK(hipGetLastError());
+    return DW_OK;
+}
+
+int dw_upload_state_f64(dw_handle* h, const double* light, const double* dark) {
+    NEED(h && light && dark, DW_EINVAL, "null argument");
+    HIPCHK(hipSetDevice(h->prm.device));
+    if (!h->L64) {
+        HIPCHK(hipMalloc(&h->L64, sizeof(double) * h->cells));
+        HIPCHK(hipMalloc(&h->D64, sizeof(double) * h->cells));
+    }
+    HIPCHK(hipMemcpyAsync(h->L64, light, sizeof(double) * h->cells, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->D64, dark, sizeof(double) * h->cells, hipMemcpyHostToDevice, h->stream));
+    const unsigned blocks = (unsigned)((h->cells + 255) / 256);
+    hipLaunchKernelGGL(f64_to_permille, dim3(blocks), dim3(256), 0, h->stream, h->L64, h->L32[h->cur], h->cells);
+    hipLaunchKernelGGL(f64_to_permille, dim3(blocks), dim3(256), 0, h->stream, h->D64, h->D32[h->cur], h->cells);
+    HIPCHK(hipGetLastError());
+    h->f64 = F64_CUR;
+    h->have_state = true;
+    h->cur_quantised = false;
+    h->stepped = false;
+    int rc = refresh_stats_f32(h);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));   // host buffers may be reused by the caller
+    return DW_OK;
+}
+
+int dw_upload_state_f32(dw_handle* h, const float* light, const float* dark, int quantised) {
+    NEED(h && light && dark, DW_EINVAL, "null argument");
+    HIPCHK(hipSetDevice(h->prm.device));
+    const int other = 1 - h->cur;   // stage natural-unit floats in the other buffer, convert in place
+    HIPCHK(hipMemcpyAsync(h->L32[other], light, sizeof(float) * h->cells, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->D32[other], dark, sizeof(float) * h->cells, hipMemcpyHostToDevice, h->stream));
+    const unsigned blocks = (unsigned)((h->cells + 255) / 256);
+    hipLaunchKernelGGL(f32nat_to_permille, dim3(blocks), dim3(256), 0, h->stream, h->L32[other], h->L32[h->cur],
+                       h->cells, quantised);
+    hipLaunchKernelGGL(f32nat_to_permille, dim3(blocks), dim3(256), 0, h->stream, h->D32[other], h->D32[h->cur],
+                       h->cells, quantised);
+    HIPCHK(hipGetLastError());
+    h->f64 = F64_NONE;
+    h->have_state = true;
+    h->cur_quantised = quantised != 0;
+    h->stepped = false;
+    int rc = refresh_stats_f32(h);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return DW_OK;
+}
+
+int dw_upload_agents(dw_handle* h, const int32_t* indices, const double* states) {
+    NEED(h, DW_EINVAL, "null handle");
+    const dw_params& p = h->prm;
+    HIPCHK(hipSetDevice(p.device));
+    const size_t bn = (size_t)p.batch * p.n_agents;
+    if (bn) {
+        NEED(indices && states, DW_EINVAL, "null argument");
+        for (size_t i = 0; i < bn; ++i) {
+            NEED(indices[2 * i] >= 0 && indices[2 * i] < p.height && indices[2 * i + 1] >= 0 &&
+                     indices[2 * i + 1] < p.width,
+                 DW_EINVAL, "agent %zu position (%d,%d) outside the %dx%d grid", i, indices[2 * i],
+                 indices[2 * i + 1], p.height, p.width);
+        }
+        HIPCHK(hipMemcpyAsync(h->idx, indices, sizeof(int) * bn * 2, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->st, states, sizeof(double) * bn, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    h->have_agents = true;
+    return DW_OK;
+}
+
+int dw_download_agents(dw_handle* h, int32_t* indices, double* states) {
+    NEED(h, DW_EINVAL, "null handle");
+    const dw_params& p = h->prm;
+    HIPCHK(hipSetDevice(p.device));
+    const size_t bn = (size_t)p.batch * p.n_agents;
+    if (bn) {
+        NEED(h->have_agents, DW_ESTATE, "no agents");
+        if (indices) HIPCHK(hipMemcpyAsync(indices, h->idx, sizeof(int) * bn * 2, hipMemcpyDeviceToHost, h->stream));
+        if (states) HIPCHK(hipMemcpyAsync(states, h->st, sizeof(double) * bn, hipMemcpyDeviceToHost, h->stream));
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return DW_OK;
+}
+
+int dw_init_random(dw_handle* h, uint64_t seed) {
+    NEED(h, DW_EINVAL, "null handle");
+    const dw_params& p = h->prm;
+    HIPCHK(hipSetDevice(p.device));
+    const dim3 g((unsigned)((p.height * p.width + 255) / 256), (unsigned)p.batch);
+    hipLaunchKernelGGL(init_random_cells, g, dim3(256), 0, h->stream, h->L32[h->cur], h->D32[h->cur], p.height,
+                       p.width, (long long)p.world_offset, (unsigned long long)seed, (float)p.light_proportion,
+                       (float)p.dark_proportion, (float)p.initial_al, (float)p.initial_ad);
+    HIPCHK(hipGetLastError());
+    if (p.n_agents) {
+        const int bn = p.batch * p.n_agents;
+        hipLaunchKernelGGL(init_random_agents, dim3((bn + 255) / 256), dim3(256), 0, h->stream, h->idx, h->st,
+                           p.batch, p.n_agents, p.height, p.width, (long long)p.world_offset,
+                           (unsigned long long)seed);
+        HIPCHK(hipGetLastError());
+    }
+    h->have_agents = true;
+    h->f64 = F64_NONE;
+    h->have_state = true;
+    h->cur_quantised = false;
+    h->stepped = false;
+    return refresh_stats_f32(h);
+}
+
+int dw_download_planes(dw_handle* h, int which, double* light, double* dark) {
+    NEED(h, DW_EINVAL, "null handle");
+    NEED(h->have_state, DW_ESTATE, "no state");
+    HIPCHK(hipSetDevice(h->prm.device));
+    NEED(which == DW_STATE_CURRENT || which == DW_STATE_PREVIOUS, DW_EINVAL, "bad state selector");
+    NEED(which == DW_STATE_CURRENT || h->stepped, DW_ESTATE, "no previous state before the first step");
+    const int buf = which == DW_STATE_CURRENT ? h->cur : 1 - h->cur;
+    const bool exact64 = (which == DW_STATE_CURRENT && h->f64 == F64_CUR) ||
+                         (which == DW_STATE_PREVIOUS && h->f64 == F64_PREV);
+    const size_t bytes = sizeof(double) * h->cells;
+    if (exact64) {
+        if (light) HIPCHK(hipMemcpyAsync(light, h->L64, bytes, hipMemcpyDeviceToHost, h->stream));
+        if (dark) HIPCHK(hipMemcpyAsync(dark, h->D64, bytes, hipMemcpyDeviceToHost, h->stream));
+    } else {
+        int rc = ensure_scratch(h, bytes);
+        if (rc) return rc;
+        const unsigned blocks = (unsigned)((h->cells + 255) / 256);
+        if (light) {
+            hipLaunchKernelGGL(permille_to_f64, dim3(blocks), dim3(256), 0, h->stream, h->L32[buf], h->scratch, h->cells);
+            HIPCHK(hipMemcpyAsync(light, h->scratch, bytes, hipMemcpyDeviceToHost, h->stream));
+        }
+        if (dark) {
+            hipLaunchKernelGGL(permille_to_f64, dim3(blocks), dim3(256), 0, h->stream, h->D32[buf], h->scratch, h->cells);
+            HIPCHK(hipMemcpyAsync(dark, h->scratch, bytes, hipMemcpyDeviceToHost, h->stream));
+        }
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return DW_OK;
+}
+
+// materialise into device scratch: grid7 and/or caches
+static int run_materialise(dw_handle* h, double L, double* d_grid7, double* d_temps, double* d_betas,
+                           double* d_growth, double* d_teff) {
+    const dw_params& p = h->prm;
+    const dim3 g((unsigned)((p.height * p.width + 255) / 256), (unsigned)p.batch);
+    const int cur = h->cur, prev = 1 - h->cur;
+    if (h->stepped) {
+        const PhysF64 P = make_f64(p, h->L_last);
+        if (h->f64 == F64_PREV)
+            hipLaunchKernelGGL((materialise<double, true>), g, dim3(256), 0, h->stream, h->L64, h->D64, h->L32[cur],
+                               h->D32[cur], p.height, p.width, P, d_grid7, d_temps, d_betas, d_growth, d_teff);
+        else
+            hipLaunchKernelGGL((materialise<float, true>), g, dim3(256), 0, h->stream, h->L32[prev], h->D32[prev],
+                               h->L32[cur], h->D32[cur], p.height, p.width, P, d_grid7, d_temps, d_betas, d_growth,
+                               d_teff);
+        HIPCHK(hipGetLastError());
+        if (d_grid7 && p.n_agents && h->have_agents) {
+            hipLaunchKernelGGL(agents_stamp, dim3((p.batch + 63) / 64), dim3(64), 0, h->stream, d_grid7, h->idx,
+                               h->st, p.batch, p.n_agents, p.height, p.width);
+            HIPCHK(hipGetLastError());
+        }
+    } else {
+        const PhysF64 P = make_f64(p, L);
+        if (h->f64 == F64_CUR)
+            hipLaunchKernelGGL((materialise<double, false>), g, dim3(256), 0, h->stream, h->L64, h->D64, h->L32[cur],
+                               h->D32[cur], p.height, p.width, P, d_grid7, d_temps, d_betas, d_growth, d_teff);
+        else
+            hipLaunchKernelGGL((materialise<float, false>), g, dim3(256), 0, h->stream, h->L32[cur], h->D32[cur],
+                               h->L32[cur], h->D32[cur], p.height, p.width, P, d_grid7, d_temps, d_betas, d_growth,
+                               d_teff);
+        HIPCHK(hipGetLastError());
+    }
+    return DW_OK;
+}
+
+int dw_download_grid(dw_handle* h, double L_init, double* grid7) {
+    NEED(h && grid7, DW_EINVAL, "null argument");
+    NEED(h->have_state, DW_ESTATE, "no state");
+    HIPCHK(hipSetDevice(h->prm.device));
+    const size_t bytes = sizeof(double) * 7 * h->cells;
+    int rc = ensure_scratch(h, bytes);
+    if (rc) return rc;
+    rc = run_materialise(h, L_init, h->scratch, nullptr, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(grid7, h->scratch, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return DW_OK;
+}
+
+int dw_download_caches(dw_handle* h, double L, double* temps, double* betas, double* growth,
+                       double* temp_effective) {
+    NEED(h, DW_EINVAL, "null handle");
+    NEED(h->have_state, DW_ESTATE, "no state");
+    HIPCHK(hipSetDevice(h->prm.device));
+    const size_t n = h->cells;
+    int rc = ensure_scratch(h, sizeof(double) * 9 * n);
+    if (rc) return rc;
+    double* d_t = h->scratch;
+    double* d_b = d_t + 3 * n;
+    double* d_g = d_b + 3 * n;
+    double* d_e = d_g + 2 * n;
+    rc = run_materialise(h, L, nullptr, temps ? d_t : nullptr, betas ? d_b : nullptr, growth ? d_g : nullptr,
+                         temp_effective ? d_e : nullptr);
+    if (rc) return rc;
+    if (temps) HIPCHK(hipMemcpyAsync(temps, d_t, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, h->stream));
+    if (betas) HIPCHK(hipMemcpyAsync(betas, d_b, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, h->stream));
+    if (growth) HIPCHK(hipMemcpyAsync(growth, d_g, sizeof(double) * 2 * n, hipMemcpyDeviceToHost, h->stream));
+    if (temp_effective) HIPCHK(hipMemcpyAsync(temp_effective, d_e, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return DW_OK;
+}
+
+// ---- the hot path -----------------------------------------------------------------------------
+
+int dw_update_agents(dw_handle* h, const int32_t* action, int32_t action_b, int32_t action_n) {
+    NEED(h && action, DW_EINVAL, "null argument");
+    HIPCHK(hipSetDevice(h->prm.device));
+    int rc = stage_host_actions(h, action, action_b, action_n);
+    if (rc) return rc;
+    return launch_agents(h, h->action_tmp, action_b, action_n);
+}
+
+int dw_step(dw_handle* h, const int32_t* action, int32_t action_b, int32_t action_n, double L) {
+    NEED(h, DW_EINVAL, "null handle");
+    HIPCHK(hipSetDevice(h->prm.device));
+    if (action) {
+        int rc = stage_host_actions(h, action, action_b, action_n);
+        if (rc) return rc;
+        rc = launch_agents(h, h->action_tmp, action_b, action_n);
+        if (rc) return rc;
+    }
+    return launch_forward(h, L);
+}
+
+int dw_step_device_actions(dw_handle* h, double L) {
+    NEED(h, DW_EINVAL, "null handle");
+    HIPCHK(hipSetDevice(h->prm.device));
+    int rc = launch_agents(h, h->action, h->prm.batch, h->prm.n_agents);
+    if (rc) return rc;
+    return launch_forward(h, L);
+}
+
+int dw_upload_actions(dw_handle* h, const int32_t* action) {
+    NEED(h && action, DW_EINVAL, "null argument");
+    HIPCHK(hipSetDevice(h->prm.device));
+    const size_t bn = (size_t)h->prm.batch * h->prm.n_agents;
+    if (bn) {
+        HIPCHK(hipMemcpyAsync(h->action, action, sizeof(int) * bn, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    return DW_OK;
+}
+
+int dw_download_actions(dw_handle* h, int32_t* action) {
+    NEED(h && action, DW_EINVAL, "null argument");
+    HIPCHK(hipSetDevice(h->prm.device));
+    const size_t bn = (size_t)h->prm.batch * h->prm.n_agents;
+    if (bn) HIPCHK(hipMemcpyAsync(action, h->action, sizeof(int) * bn, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return DW_OK;
+}
+
+int dw_step_n(dw_handle* h, int32_t nsteps, double* L_io, double dL, double min_L, double max_L,
+              int use_device_actions) {
+    NEED(h && L_io, DW_EINVAL, "null argument");
+    NEED(nsteps >= 0, DW_EINVAL, "nsteps < 0");
+    HIPCHK(hipSetDevice(h->prm.device));
+    double L = *L_io;
+    for (int s = 0; s < nsteps; ++s) {
+        int rc;
+        if (use_device_actions) {
+            rc = launch_agents(h, h->action, h->prm.batch, h->prm.n_agents);
+            if (rc) return rc;
+        }
+        rc = launch_forward(h, L);
+        if (rc) return rc;
+        L += dL;                                           // ref update_L :471-473
+        L = L > max_L ? max_L : L;
+        L = L < min_L ? min_L : L;
+    }
+    *L_io = L;
+    return DW_OK;
+}
+
+int dw_forward_f64(dw_handle* h, const double* light, const double* dark, double L, double* grid7,
+                   double* temps, double* betas, double* growth, double* temp_effective) {
+    NEED(h && light && dark && grid7, DW_EINVAL, "null argument");
+    const dw_params& p = h->prm;
+    HIPCHK(hipSetDevice(p.device));
+    const size_t n = h->cells;
+    // scratch layout: [in light n][in dark n][grid7 7n][caches 9n] doubles, [new light n][new dark n] floats
+    int rc = ensure_scratch(h, sizeof(double) * 18 * n + sizeof(float) * 2 * n);
+    if (rc) return rc;
+    double* dL = h->scratch;
+    double* dD = dL + n;
+    double* dG = dD + n;
+    double* d_t = dG + 7 * n;
+    double* d_b = d_t + 3 * n;
+    double* d_g = d_b + 3 * n;
+    double* d_e = d_g + 2 * n;
+    float* nL = reinterpret_cast<float*>(d_e + n);
+    float* nD = nL + n;
+    HIPCHK(hipMemcpyAsync(dL, light, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(dD, dark, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
+    const PhysF32 P = derive_f32(p, L);
+    const PhysF64 P64 = make_f64(p, L);
+    const dim3 g((unsigned)((p.height * p.width + 255) / 256), (unsigned)p.batch);
+    // the reductions of this side computation must not disturb the handle's per-world stats
+    StatsDev* tmp_stats = nullptr;
+    HIPCHK(hipMalloc(&tmp_stats, sizeof(StatsDev) * p.batch + sizeof(unsigned long long)));
+    HIPCHK(hipMemsetAsync(tmp_stats, 0, sizeof(StatsDev) * p.batch + sizeof(unsigned long long), h->stream));
+    unsigned long long* tmp_fix = reinterpret_cast<unsigned long long*>(tmp_stats + p.batch);
+    hipLaunchKernelGGL((step_generic<double, 2>), g, dim3(256), 0, h->stream, dL, dD, nL, nD, p.height, p.width, P,
+                       P64, tmp_stats, tmp_fix);
+    hipLaunchKernelGGL((materialise<double, true>), g, dim3(256), 0, h->stream, dL, dD, nL, nD, p.height, p.width,
+                       P64, dG, temps ? d_t : (double*)nullptr, betas ? d_b : (double*)nullptr,
+                       growth ? d_g : (double*)nullptr, temp_effective ? d_e : (double*)nullptr);
+    hipError_t le = hipGetLastError();
+    if (le == hipSuccess && p.n_agents && h->have_agents) {
+        hipLaunchKernelGGL(agents_stamp, dim3((p.batch + 63) / 64), dim3(64), 0, h->stream, dG, h->idx, h->st,
+                           p.batch, p.n_agents, p.height, p.width);
+        le = hipGetLastError();
+    }
+    if (le == hipSuccess) le = hipMemcpyAsync(grid7, dG, sizeof(double) * 7 * n, hipMemcpyDeviceToHost, h->stream);
+    if (le == hipSuccess && temps) le = hipMemcpyAsync(temps, d_t, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, h->stream);
+    if (le == hipSuccess && betas) le = hipMemcpyAsync(betas, d_b, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, h->stream);
+    if (le == hipSuccess && growth) le = hipMemcpyAsync(growth, d_g, sizeof(double) * 2 * n, hipMemcpyDeviceToHost, h->stream);
+    if (le == hipSuccess && temp_effective)
+        le = hipMemcpyAsync(temp_effective, d_e, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream);
+    if (le == hipSuccess) le = hipStreamSynchronize(h->stream);
+    (void)hipFree(tmp_stats);
+    if (le != hipSuccess) return fail(DW_EHIP, "dw_forward_f64: %s", hipGetErrorString(le));
+    return DW_OK;
+}
+
+int dw_get_obs(dw_handle* h, double L_init, double* obs) {
+    NEED(h, DW_EINVAL, "null handle");
+    const dw_params& p = h->prm;
+    HIPCHK(hipSetDevice(p.device));
+    const size_t bn = (size_t)p.batch * p.n_agents;
+    if (bn == 0) return DW_OK;
+    NEED(obs, DW_EINVAL, "null obs");
+    NEED(h->have_state && h->have_agents, DW_ESTATE, "no state / agents");
+    int rc = ensure_scratch(h, sizeof(double) * bn * 63);
+    if (rc) return rc;
+    const int threads = (int)(bn * 9);
+    const dim3 g((threads + 127) / 128);
+    const int cur = h->cur, prev = 1 - h->cur;
+    if (h->stepped) {
+        const PhysF64 P = make_f64(p, h->L_last);
+        if (h->f64 == F64_PREV)
+            hipLaunchKernelGGL((observe<double, true>), g, dim3(128), 0, h->stream, h->L64, h->D64, h->L32[cur],
+                               h->D32[cur], h->idx, h->st, p.batch, p.n_agents, p.height, p.width, P, p.obs_mask,
+                               h->scratch);
+        else
+            hipLaunchKernelGGL((observe<float, true>), g, dim3(128), 0, h->stream, h->L32[prev], h->D32[prev],
+                               h->L32[cur], h->D32[cur], h->idx, h->st, p.batch, p.n_agents, p.height, p.width, P,
+                               p.obs_mask, h->scratch);
+    } else {
+        const PhysF64 P = make_f64(p, L_init);
+        if (h->f64 == F64_CUR)
+            hipLaunchKernelGGL((observe<double, false>), g, dim3(128), 0, h->stream, h->L64, h->D64, h->L32[cur],
+                               h->D32[cur], h->idx, h->st, p.batch, p.n_agents, p.height, p.width, P, p.obs_mask,
+                               h->scratch);
+        else
+            hipLaunchKernelGGL((observe<float, false>), g, dim3(128), 0, h->stream, h->L32[cur], h->D32[cur],
+                               h->L32[cur], h->D32[cur], h->idx, h->st, p.batch, p.n_agents, p.height, p.width, P,
+                               p.obs_mask, h->scratch);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(obs, h->scratch, sizeof(double) * bn * 63, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return DW_OK;
+}
+
+int dw_get_reward_done(dw_handle* h, double* reward, uint8_t* done) {
+    NEED(h, DW_EINVAL, "null handle");
+    const dw_params& p = h->prm;
+    HIPCHK(hipSetDevice(p.device));
+    const int bn = p.batch * p.n_agents;
+    if (bn == 0) return DW_OK;
+    NEED(h->have_agents, DW_ESTATE, "no agents");
+    hipLaunchKernelGGL(reward_done, dim3((bn + 255) / 256), dim3(256), 0, h->stream, h->st, h->reward_d, h->done_d, bn);
+    HIPCHK(hipGetLastError());
+    if (reward) HIPCHK(hipMemcpyAsync(reward, h->reward_d, sizeof(double) * bn, hipMemcpyDeviceToHost, h->stream));
+    if (done) HIPCHK(hipMemcpyAsync(done, h->done_d, (size_t)bn, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return DW_OK;
+}
+
+int dw_reduce(dw_handle* h, dw_world_stats* per_world) {
+    NEED(h && per_world, DW_EINVAL, "null argument");
+    NEED(h->have_state, DW_ESTATE, "no state");
+    static_assert(sizeof(dw_world_stats) == sizeof(StatsDev), "stats layout");
+    HIPCHK(hipSetDevice(h->prm.device));
+    HIPCHK(hipMemcpyAsync(per_world, h->stats, sizeof(StatsDev) * h->prm.batch, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return DW_OK;
+}
+
+int dw_policy_greedy(dw_handle* h, int mode) {
+    NEED(h, DW_EINVAL, "null handle");
+    const dw_params& p = h->prm;
+    HIPCHK(hipSetDevice(p.device));
+    const int bn = p.batch * p.n_agents;
+    if (bn == 0) return DW_OK;
+    NEED(h->have_state && h->have_agents, DW_ESTATE, "no state / agents");
+    NEED(mode == DW_POLICY_ARGMAX || mode == DW_POLICY_ARGMIN, DW_EINVAL, "bad policy mode");
+    NEED(h->cur_quantised || h->f64 != F64_CUR, DW_ESTATE,
+         "device policy on an exact float64 initial state is not supported; compute the action on the host");
+    hipLaunchKernelGGL(policy_greedy, dim3((bn + 255) / 256), dim3(256), 0, h->stream, h->L32[h->cur], h->D32[h->cur],
+                       h->idx, p.batch, p.n_agents, p.height, p.width, p.obs_mask, mode == DW_POLICY_ARGMIN ? 1 : 0,
+                       h->action);
+    HIPCHK(hipGetLastError());
+    return DW_OK;
+}
+
+int dw_lifespan_reset(dw_handle* h) {
+    NEED(h, DW_EINVAL, "null handle");
+    const dw_params& p = h->prm;
+    HIPCHK(hipSetDevice(p.device));
+    const size_t bn = (size_t)p.batch * (p.n_agents > 0 ? p.n_agents : 1);
+    HIPCHK(hipMemsetAsync(h->done_at, 0, sizeof(int) * p.batch, h->stream));
+    HIPCHK(hipMemsetAsync(h->agents_done_at, 0, sizeof(int) * bn, h->stream));
+    HIPCHK(hipMemsetAsync(h->n_alive, 0, sizeof(int), h->stream));
+    return DW_OK;
+}
+
+int dw_lifespan_accumulate(dw_handle* h, uint32_t threshold_k) {
+    NEED(h, DW_EINVAL, "null handle");
+    const dw_params& p = h->prm;
+    HIPCHK(hipSetDevice(p.device));
+    HIPCHK(hipMemsetAsync(h->n_alive, 0, sizeof(int), h->stream));
+    const int n = p.batch * (p.n_agents > 0 ? p.n_agents : 1);
+    hipLaunchKernelGGL(lifespan_accumulate, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->stats, h->st, p.batch,
+                       p.n_agents, threshold_k, h->done_at, h->agents_done_at, h->n_alive);
+    HIPCHK(hipGetLastError());
+    return DW_OK;
+}
+
+int dw_lifespan_download(dw_handle* h, int32_t* done_at, int32_t* agents_done_at, int32_t* n_worlds_alive) {
+    NEED(h, DW_EINVAL, "null handle");
+    const dw_params& p = h->prm;
+    HIPCHK(hipSetDevice(p.device));
+    if (done_at) HIPCHK(hipMemcpyAsync(done_at, h->done_at, sizeof(int) * p.batch, hipMemcpyDeviceToHost, h->stream));
+    if (agents_done_at && p.n_agents)
+        HIPCHK(hipMemcpyAsync(agents_done_at, h->agents_done_at, sizeof(int) * (size_t)p.batch * p.n_agents,
+                              hipMemcpyDeviceToHost, h->stream));
+    if (n_worlds_alive) HIPCHK(hipMemcpyAsync(n_worlds_alive, h->n_alive, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return DW_OK;
+}
+
+// ---- plumbing ---------------------------------------------------------------------------------
+
+int dw_set_stream(dw_handle* h, void* hip_stream) {
+    NEED(h, DW_EINVAL, "null handle");
+    HIPCHK(hipSetDevice(h->prm.device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->own_stream) HIPCHK(hipStreamDestroy(h->stream));
+    h->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    h->own_stream = false;
+    return DW_OK;
+}
+
+int dw_sync(dw_handle* h) {
+    NEED(h, DW_EINVAL, "null handle");
+    HIPCHK(hipSetDevice(h->prm.device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return DW_OK;
+}
+
+int dw_timer_start(dw_handle* h) {
+    NEED(h, DW_EINVAL, "null handle");
+    HIPCHK(hipSetDevice(h->prm.device));
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    return DW_OK;
+}
+
+int dw_timer_stop(dw_handle* h, float* elapsed_ms) {
+    NEED(h && elapsed_ms, DW_EINVAL, "null argument");
+    HIPCHK(hipSetDevice(h->prm.device));
+    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    HIPCHK(hipEventSynchronize(h->ev1));
+    HIPCHK(hipEventElapsedTime(elapsed_ms, h->ev0, h->ev1));
+    return DW_OK;
+}
+
+int dw_device_planes(dw_handle* h, int which, void** light, void** dark) {
+    NEED(h && light && dark, DW_EINVAL, "null argument");
+    NEED(which == DW_STATE_CURRENT || which == DW_STATE_PREVIOUS, DW_EINVAL, "bad state selector");
+    const int buf = which == DW_STATE_CURRENT ? h->cur : 1 - h->cur;
+    *light = h->L32[buf];
+    *dark = h->D32[buf];
+    return DW_OK;
+}
+
+int dw_kernel_info(dw_handle* h, char* buf, size_t buflen) {
+    NEED(h && buf && buflen, DW_EINVAL, "null argument");
+    const dw_params& p = h->prm;
+    const char* prec = p.precision == DW_PRECISION_EXACT ? "exact" : (p.precision == DW_PRECISION_FAST ? "fast" : "f64");
+    if (h->tcq) {
+        const int TR = (256 / h->tcq) * h->rpt;
+        snprintf(buf, buflen,
+                 "step_tiled<TCQ=%d,RPT=%d,%s> tile=%dx%d cells, %zu B LDS/workgroup, %d tiles, grid=%d x 256 threads, "
+                 "XCD-chunked",
+                 h->tcq, h->rpt, prec, TR, h->tcq * 4, h->tile_lds, h->geom.ntiles, h->geom.chunk * 8);
+    } else {
+        snprintf(buf, buflen, "step_generic<%s> one thread per cell, grid=(%d,%d) x 256 threads", prec,
+                 (p.height * p.width + 255) / 256, p.batch);
+    }
+    return DW_OK;
+}
+
+int dw_last_fixup_count(dw_handle* h, uint64_t* count) {
+    NEED(h && count, DW_EINVAL, "null argument");
+    HIPCHK(hipSetDevice(h->prm.device));
+    unsigned long long v = 0;
+    HIPCHK(hipMemcpyAsync(&v, h->fixups, sizeof(v), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    *count = v;
+    return DW_OK;
+}
+
+}  // extern "C"

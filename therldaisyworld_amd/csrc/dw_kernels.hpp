@@ -1,0 +1,676 @@
+// dw_kernels.hpp — HIP kernels of the RLDaisyWorld hot path for gfx950 (MI355X).
+//
+//   step_tiled      the hot kernel: fused 3x3 toroidal stencil + albedo/temperature/growth reaction
+//                   + 3-decimal quantiser + per-world reductions, LDS-staged tile with halo.
+//   step_generic    one thread per cell, any grid shape, float64 or float32: the in-library
+//                   reference, the first step from an un-quantised state, odd shapes.
+//   agents_update   ref update_agents (daisy_world_rl.py:181-244)
+//   observe         ref get_obs (:246-263) + the channel values forward() would have written
+//   materialise     ref self.grid after forward() (:445-459) / initialize_grid (:304-323)
+//   policy_greedy   ref Greedy.__call__ deterministic branch (agents/greedy.py:14-36)
+//   init_random     synthetic initial state (ref :285-302, :173-179) from Philox4x32-10
+//
+// Wavefront = 64 lanes, 256-thread workgroups (4 waves), no MFMA: the step is HBM-bound
+// (16 algorithmic bytes per cell-update, ~90 VALU issue slots per cell).
+#pragma once
+#include "dw_physics.hpp"
+
+namespace dw {
+
+struct StatsDev {             // mirrors dw_world_stats
+    unsigned int max_k;
+    unsigned int reserved;
+    unsigned long long sum_l;
+    unsigned long long sum_d;
+};
+
+struct Geom {
+    int B, H, W;
+    int Wq;                   // W / 4 (tiled kernel only)
+    int tiles_r, tiles_c;     // tiles per world
+    int ntiles;               // B * tiles_r * tiles_c
+    int chunk;                // ceil(ntiles / 8): tiles per XCD
+};
+
+// ---------------------------------------------------------------------------------------------
+// wave / workgroup reductions (wavefront shuffles, 64 lanes)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// input adaptors: natural-unit float64 planes, or per-mille float32 planes
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double to_natural(double x) { return x; }
+__device__ __forceinline__ double to_natural(float k) { return (double)k / 1000.0; }
+__device__ __forceinline__ float to_permille(double x) { return (float)(x * 1000.0); }
+__device__ __forceinline__ float to_permille(float k) { return k; }
+
+template <typename T>
+__device__ __forceinline__ void gather9(const T* __restrict__ plane, int H, int W, int r, int c,
+                                        double out[9]) {
+    const int ru = r == 0 ? H - 1 : r - 1, rd = r == H - 1 ? 0 : r + 1;
+    const int cl = c == 0 ? W - 1 : c - 1, cr = c == W - 1 ? 0 : c + 1;
+    const int rows[3] = {ru, r, rd}, cols[3] = {cl, c, cr};
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) out[a * 3 + b] = to_natural(plane[(size_t)rows[a] * W + cols[b]]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// step_generic: grid = (ceil(H*W/256), B), block = 256.  PREC: 0 exact, 1 fast, 2 f64.
+// ---------------------------------------------------------------------------------------------
+template <typename InT, int PREC>
+__global__ __launch_bounds__(256) void step_generic(const InT* __restrict__ inL,
+                                                    const InT* __restrict__ inD,
+                                                    float* __restrict__ outL,
+                                                    float* __restrict__ outD, int H, int W,
+                                                    PhysF32 P, PhysF64 P64,
+                                                    StatsDev* __restrict__ stats,
+                                                    unsigned long long* __restrict__ fixups) {
+    const int b = blockIdx.y;
+    const int cell = blockIdx.x * 256 + threadIdx.x;
+    const size_t woff = (size_t)b * H * W;
+    float kl = 0.f, kd = 0.f;
+    bool fixed = false;
+    if (cell < H * W) {
+        const int r = cell / W, c = cell - r * W;
+        const InT* pl = inL + woff;
+        const InT* pd = inD + woff;
+        if (PREC == 2) {
+            double l9[9], d9[9];
+            gather9(pl, H, W, r, c, l9);
+            gather9(pd, H, W, r, c, d9);
+            const CellF64 o = cell_f64(P64, l9, d9);
+            kl = (float)dw_round3_k(o.nl);
+            kd = (float)dw_round3_k(o.nd);
+        } else {
+            const int ru = r == 0 ? H - 1 : r - 1, rd = r == H - 1 ? 0 : r + 1;
+            const int cl = c == 0 ? W - 1 : c - 1, cr = c == W - 1 ? 0 : c + 1;
+#define DW_AT(p, rr, cc) to_permille((p)[(size_t)(rr) * W + (cc)])
+            const float li = DW_AT(pl, r, c), di = DW_AT(pd, r, c);
+            const float El = (DW_AT(pl, ru, c) + DW_AT(pl, rd, c)) + (DW_AT(pl, r, cl) + DW_AT(pl, r, cr));
+            const float Cl = (DW_AT(pl, ru, cl) + DW_AT(pl, rd, cl)) + (DW_AT(pl, ru, cr) + DW_AT(pl, rd, cr));
+            const float Ed = (DW_AT(pd, ru, c) + DW_AT(pd, rd, c)) + (DW_AT(pd, r, cl) + DW_AT(pd, r, cr));
+            const float Cd = (DW_AT(pd, ru, cl) + DW_AT(pd, rd, cl)) + (DW_AT(pd, ru, cr) + DW_AT(pd, rd, cr));
+#undef DW_AT
+            const GrowthF32 g = growth_f32(P, li, di, El, Cl, Ed, Cd);
+            if (PREC == 1) {
+                kl = finish_fast(li, g.gql);
+                kd = finish_fast(di, g.gqd);
+            } else {
+                bool tl, td;
+                kl = finish_exact(P, li, g.gql, g.dKl, g.oml, tl);
+                kd = finish_exact(P, di, g.gqd, g.dKd, g.omd, td);
+                if (tl || td) {
+                    double l9[9], d9[9];
+                    gather9(pl, H, W, r, c, l9);
+                    gather9(pd, H, W, r, c, d9);
+                    const CellF64 o = cell_f64(P64, l9, d9);
+                    kl = (float)dw_round3_k(o.nl);
+                    kd = (float)dw_round3_k(o.nd);
+                    fixed = true;
+                }
+            }
+        }
+        outL[woff + cell] = kl;
+        outD[woff + cell] = kd;
+    }
+    // per-world reductions: wave shuffles, then one set of atomics per wave
+    const float m = wave_max(fmaxf(kl, kd));
+    const float sl = wave_sum(kl), sd = wave_sum(kd);
+    const unsigned long long nf = __popcll(__ballot(fixed));
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(&stats[b].max_k, (unsigned int)m);
+        atomicAdd(&stats[b].sum_l, (unsigned long long)sl);
+        atomicAdd(&stats[b].sum_d, (unsigned long long)sd);
+        if (nf) atomicAdd(fixups, nf);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// step_tiled — the hot kernel.
+//
+// One 256-thread workgroup updates a tile of TR = (256/TCQ)*RPT rows x 4*TCQ columns of one
+// world.  Phase 1 stages the tile plus a one-cell toroidal halo (one row above/below, one 16-byte
+// column group left/right; wrap resolved here) of both planes into LDS with coalesced 16-byte
+// loads.  Phase 2: each thread owns 4 adjacent columns and walks RPT rows with a 3-row register
+// window; per row it needs three ds_read_b128 per plane (its group and the two neighbours).
+// Phase 3 (exact mode): cells whose float32 pre-rounding value is within the error bound of a
+// rounding tie were queued in LDS; they are re-evaluated in float64 from the LDS tile and patched
+// in global memory.  Per-world max/sums are reduced with wavefront shuffles and LDS atomics and
+// leave the workgroup as three global atomics.
+//
+// Workgroup -> tile mapping is XCD-aware: hardware deals consecutive workgroup ids round-robin to
+// the 8 XCDs, so id b works on tile (b % 8) * chunk + b / 8: each XCD (and its private L2) gets a
+// contiguous run of tiles, and the halo rows shared by vertically adjacent tiles hit in L2.
+// ---------------------------------------------------------------------------------------------
+constexpr int kMaxFix = 1024;
+
+template <int TCQ, int RPT>
+struct TileCfg {
+    static constexpr int RG = 256 / TCQ;          // row groups per workgroup
+    static constexpr int TR = RG * RPT;           // tile rows
+    static constexpr int LROWS = TR + 2;          // + halo rows
+    static constexpr int LQ = TCQ + 2;            // float4 groups per LDS row (+ halo groups)
+    static constexpr int LSTRIDE = LQ * 4;        // floats per LDS row
+    static constexpr int PLANE = LROWS * LSTRIDE; // floats per plane
+    static constexpr int STAGE_ITERS = (LROWS * LQ + 255) / 256;
+    static constexpr size_t LDS_BYTES = (size_t)2 * PLANE * sizeof(float);
+};
+
+struct Row4 {                 // 4 centre values of a row and the horizontal pair sums around them
+    float x[4];
+    float h2[4];              // h2[i] = x[i-1] + x[i+1]
+};
+
+__device__ __forceinline__ Row4 load_row(const float* __restrict__ lds_row_group) {
+    // lds_row_group points at the float4 group LEFT of the thread's own group
+    const float4 a = *reinterpret_cast<const float4*>(lds_row_group);
+    const float4 m = *reinterpret_cast<const float4*>(lds_row_group + 4);
+    const float4 c = *reinterpret_cast<const float4*>(lds_row_group + 8);
+    Row4 r;
+    r.x[0] = m.x; r.x[1] = m.y; r.x[2] = m.z; r.x[3] = m.w;
+    r.h2[0] = a.w + m.y;
+    r.h2[1] = m.x + m.z;
+    r.h2[2] = m.y + m.w;
+    r.h2[3] = m.z + c.x;
+    return r;
+}
+
+// float64 re-evaluation of the cell at LDS (row j, column col); tile_org is the global offset of
+// LDS position (0, 0) (which is one row above / one group left of the tile).
+template <class C>
+__device__ __forceinline__ void fix_cell(const float* lds, int j, int col, const PhysF64& P64,
+                                         float* __restrict__ outL, float* __restrict__ outD,
+                                         long long tile_org, int W, unsigned int* s_max,
+                                         unsigned int* s_suml, unsigned int* s_sumd) {
+    double l9[9], d9[9];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int o = (j - 1 + a) * C::LSTRIDE + (col - 1 + c);
+            l9[a * 3 + c] = (double)lds[o] / 1000.0;
+            d9[a * 3 + c] = (double)lds[C::PLANE + o] / 1000.0;
+        }
+    const CellF64 o = cell_f64(P64, l9, d9);
+    const float kl = (float)dw_round3_k(o.nl), kd = (float)dw_round3_k(o.nd);
+    const long long off = tile_org + (long long)j * W + col;
+    outL[off] = kl;
+    outD[off] = kd;
+    atomicMax(s_max, (unsigned int)fmaxf(kl, kd));
+    atomicAdd(s_suml, (unsigned int)kl);
+    atomicAdd(s_sumd, (unsigned int)kd);
+}
+
+template <int TCQ, int RPT, bool EXACT>
+__global__ __launch_bounds__(256) void step_tiled(const float* __restrict__ inL,
+                                                  const float* __restrict__ inD,
+                                                  float* __restrict__ outL,
+                                                  float* __restrict__ outD, Geom G, PhysF32 P,
+                                                  PhysF64 P64, StatsDev* __restrict__ stats,
+                                                  unsigned long long* __restrict__ fixups) {
+    using C = TileCfg<TCQ, RPT>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ unsigned int s_fix[EXACT ? kMaxFix : 1];
+    __shared__ unsigned int s_nfix, s_max, s_suml, s_sumd;
+
+    // ---- XCD-aware tile id ----
+    const int bid = blockIdx.x;
+    const int t = (bid & 7) * G.chunk + (bid >> 3);
+    if (t >= G.ntiles) return;                      // uniform for the whole workgroup
+    const int tiles_per_world = G.tiles_r * G.tiles_c;
+    const int b = t / tiles_per_world;
+    const int tw = t - b * tiles_per_world;
+    const int tr = tw / G.tiles_c, tc = tw - tr * G.tiles_c;
+    const int r0 = tr * C::TR, q0 = tc * TCQ;
+    const int nrows = min(C::TR, G.H - r0);
+    const int nq = min(TCQ, G.Wq - q0);
+    const int tid = threadIdx.x;
+    const size_t woff = (size_t)b * G.H * G.W;
+
+    if (tid == 0) { s_nfix = 0; s_max = 0; s_suml = 0; s_sumd = 0; }
+
+    // ---- phase 1: stage tile + halo into LDS (all loads issued before the first LDS write) ----
+    {
+        const int lrows = nrows + 2, lq = nq + 2;
+        float4 vl[C::STAGE_ITERS], vd[C::STAGE_ITERS];
+#pragma unroll
+        for (int it = 0; it < C::STAGE_ITERS; ++it) {
+            const int idx = it * 256 + tid;
+            // out-of-range slots are clamped onto a valid address (their value is never stored)
+            const int j = min(idx / C::LQ, lrows - 1), gq = min(idx % C::LQ, lq - 1);
+            int rr = r0 - 1 + j;
+            rr = rr < 0 ? rr + G.H : (rr >= G.H ? rr - G.H : rr);
+            int gg = q0 - 1 + gq;
+            gg = gg < 0 ? gg + G.Wq : (gg >= G.Wq ? gg - G.Wq : gg);
+            const size_t off = woff + (size_t)rr * G.W + (size_t)gg * 4;
+            vl[it] = *reinterpret_cast<const float4*>(inL + off);
+            vd[it] = *reinterpret_cast<const float4*>(inD + off);
+        }
+#pragma unroll
+        for (int it = 0; it < C::STAGE_ITERS; ++it) {
+            const int idx = it * 256 + tid;
+            const int j = idx / C::LQ, gq = idx - j * C::LQ;
+            if (j < lrows && gq < lq) {
+                *reinterpret_cast<float4*>(lds + j * C::LSTRIDE + gq * 4) = vl[it];
+                *reinterpret_cast<float4*>(lds + C::PLANE + j * C::LSTRIDE + gq * 4) = vd[it];
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2: 4 columns x RPT rows per thread, 3-row register window ----
+    const int cq = tid % TCQ, rg = tid / TCQ;
+    const int jr0 = rg * RPT;
+    float acc_max = 0.f, acc_l = 0.f, acc_d = 0.f;
+    if (cq < nq && jr0 < nrows) {
+        const float* baseL = lds + cq * 4;               // group left of mine, LDS row 0
+        const float* baseD = baseL + C::PLANE;
+        Row4 upL = load_row(baseL + (jr0 + 0) * C::LSTRIDE);
+        Row4 upD = load_row(baseD + (jr0 + 0) * C::LSTRIDE);
+        Row4 miL = load_row(baseL + (jr0 + 1) * C::LSTRIDE);
+        Row4 miD = load_row(baseD + (jr0 + 1) * C::LSTRIDE);
+#pragma unroll
+        for (int rr = 0; rr < RPT; ++rr) {
+            const int row = jr0 + rr;                    // tile-local row; LDS row = row + 1
+            if (row < nrows) {
+                const Row4 dnL = load_row(baseL + (row + 2) * C::LSTRIDE);
+                const Row4 dnD = load_row(baseD + (row + 2) * C::LSTRIDE);
+                float ol[4], od[4];
+                unsigned int ties = 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float El = miL.h2[i] + (upL.x[i] + dnL.x[i]);
+                    const float Cl = upL.h2[i] + dnL.h2[i];
+                    const float Ed = miD.h2[i] + (upD.x[i] + dnD.x[i]);
+                    const float Cd = upD.h2[i] + dnD.h2[i];
+                    const GrowthF32 g = growth_f32(P, miL.x[i], miD.x[i], El, Cl, Ed, Cd);
+                    if (EXACT) {
+                        bool tl, td;
+                        ol[i] = finish_exact(P, miL.x[i], g.gql, g.dKl, g.oml, tl);
+                        od[i] = finish_exact(P, miD.x[i], g.gqd, g.dKd, g.omd, td);
+                        const bool tie = tl || td;
+                        ties |= (tie ? 1u : 0u) << i;
+                        const float sl_ = tie ? 0.f : ol[i], sd_ = tie ? 0.f : od[i];
+                        acc_l += sl_; acc_d += sd_;
+                        acc_max = fmaxf(acc_max, fmaxf(sl_, sd_));
+                    } else {
+                        ol[i] = finish_fast(miL.x[i], g.gql);
+                        od[i] = finish_fast(miD.x[i], g.gqd);
+                        acc_l += ol[i]; acc_d += od[i];
+                        acc_max = fmaxf(acc_max, fmaxf(ol[i], od[i]));
+                    }
+                }
+                const size_t off = woff + (size_t)(r0 + row) * G.W + (size_t)(q0 + cq) * 4;
+                *reinterpret_cast<float4*>(outL + off) = make_float4(ol[0], ol[1], ol[2], ol[3]);
+                *reinterpret_cast<float4*>(outD + off) = make_float4(od[0], od[1], od[2], od[3]);
+                if (EXACT && ties) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (ties & (1u << i)) {
+                            const unsigned int slot = atomicAdd(&s_nfix, 1u);
+                            if (slot < (unsigned)kMaxFix)
+                                s_fix[slot] = ((unsigned)(row + 1) << 16) | (unsigned)((cq + 1) * 4 + i);
+                            else   // queue full: re-evaluate right here (after my own float4 store)
+                                fix_cell<C>(lds, row + 1, (cq + 1) * 4 + i, P64, outL, outD,
+                                            (long long)woff + (long long)(r0 - 1) * G.W + (long long)q0 * 4 - 4, G.W,
+                                            &s_max, &s_suml, &s_sumd);
+                        }
+                    }
+                }
+                upL = miL; upD = miD; miL = dnL; miD = dnD;
+            }
+        }
+    }
+
+    // ---- per-world reductions: wavefront shuffles, then LDS atomics ----
+    {
+        const float m = wave_max(acc_max);
+        const float sl = wave_sum(acc_l), sd = wave_sum(acc_d);
+        if ((tid & 63) == 0) {
+            atomicMax(&s_max, (unsigned int)m);
+            atomicAdd(&s_suml, (unsigned int)sl);
+            atomicAdd(&s_sumd, (unsigned int)sd);
+        }
+    }
+
+    // ---- phase 3 (exact mode): float64 re-evaluation of the queued near-tie cells ----
+    if (EXACT) {
+        __syncthreads();   // also orders the float4 stores above before the patch stores below
+        const unsigned int nq_fix = min(s_nfix, (unsigned)kMaxFix);
+        for (unsigned int e = tid; e < nq_fix; e += 256) {
+            const unsigned int ent = s_fix[e];
+            fix_cell<C>(lds, (int)(ent >> 16), (int)(ent & 0xffffu), P64, outL, outD,
+                        (long long)woff + (long long)(r0 - 1) * G.W + (long long)q0 * 4 - 4, G.W, &s_max, &s_suml,
+                        &s_sumd);
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        atomicMax(&stats[b].max_k, s_max);
+        atomicAdd(&stats[b].sum_l, (unsigned long long)s_suml);
+        atomicAdd(&stats[b].sum_d, (unsigned long long)s_sumd);
+        if (EXACT && s_nfix) atomicAdd(fixups, (unsigned long long)s_nfix);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// agents_update — ref update_agents (daisy_world_rl.py:181-244), collision_mode 0.
+// One thread per world walks its agents IN ORDER (the first agent to land on a cell eats it all).
+// Energy stores are float64 and updated with exactly the reference's operations, so alive/dead
+// decisions and rewards are bit-identical.  `f64L/f64D` (natural units) are the exact copies of an
+// un-quantised initial state when present (else nullptr).
+// ---------------------------------------------------------------------------------------------
+__global__ void agents_update(float* __restrict__ L32, float* __restrict__ D32,
+                              double* __restrict__ f64L, double* __restrict__ f64D,
+                              int* __restrict__ idx, double* __restrict__ st,
+                              const int* __restrict__ action, int act_b, int act_n, int B, int N,
+                              int H, int W, double agent_gamma) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const size_t woff = (size_t)b * H * W;
+    for (int n = 0; n < N; ++n) st[(size_t)b * N + n] -= agent_gamma;           // ref :184
+    if (b < act_b) {
+        for (int n = 0; n < act_n && n < N; ++n) {                               // ref :186-187
+            double s = st[(size_t)b * N + n];
+            if (s > 0.0) {                                                       // ref :189
+                const int a = action[(size_t)b * act_n + n];
+                int r = idx[((size_t)b * N + n) * 2 + 0], c = idx[((size_t)b * N + n) * 2 + 1];
+                if (a != 8) {                                                    // ref :191-206
+                    const int m = ((a % 4) + 4) % 4;
+                    if (m == 0) c -= 1; else if (m == 1) r -= 1; else if (m == 2) r += 1; else c += 1;
+                }
+                r = ((r % H) + H) % H;                                           // ref :208
+                c = ((c % W) + W) % W;
+                idx[((size_t)b * N + n) * 2 + 0] = r;
+                idx[((size_t)b * N + n) * 2 + 1] = c;
+                if (a > 4) {                                                     // ref :210-216
+                    const size_t o = woff + (size_t)r * W + c;
+                    double l, d;
+                    if (f64L) { l = f64L[o]; d = f64D[o]; f64L[o] = 0.0; f64D[o] = 0.0; }
+                    else { l = (double)L32[o] / 1000.0; d = (double)D32[o] / 1000.0; }
+                    s += l + d;
+                    L32[o] = 0.f; D32[o] = 0.f;
+                    st[(size_t)b * N + n] = s;
+                }
+            }
+        }
+    }
+    for (int n = 0; n < N; ++n) {                                                // ref :244
+        const double s = st[(size_t)b * N + n];
+        st[(size_t)b * N + n] = s < 0.0 ? 0.0 : (s > 1.0 ? 1.0 : s);
+    }
+}
+
+// reward / done (ref step :486-492, N > 0):  reward = state * (state > 0); done = reward < 0.1
+__global__ void reward_done(const double* __restrict__ st, double* __restrict__ reward,
+                            unsigned char* __restrict__ done, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double s = st[i];
+    const double r = s * (s > 0.0 ? 1.0 : 0.0);
+    reward[i] = r;
+    done[i] = r < 0.1 ? 1 : 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// materialise — the reference's 7-channel float64 grid.
+//   after a step (POST=true): prev = pre-step covers (post-graze), cur = quantised new covers:
+//       ch0 = round3(p - nl - nd) from the un-rounded clipped covers (ref :450,452),
+//       ch1/2 = cur/1000, ch3..5 = round3(T, T_light, T_dark) of prev (ref :446-448), ch6 = 0.
+//   after an upload (POST=false): prev = the initial covers; ch0..2 un-rounded, ch3..5 un-rounded
+//       temperatures (ref :310-323).
+// caches (optional): temps[3], betas[3], growth[2], temp_effective — un-rounded (ref :345-419).
+// Agent states are written into channel 4 afterwards by agents_stamp (ref :454-459).
+// ---------------------------------------------------------------------------------------------
+template <typename PrevT, bool POST>
+__global__ __launch_bounds__(256) void materialise(const PrevT* __restrict__ pL,
+                                                   const PrevT* __restrict__ pD,
+                                                   const float* __restrict__ cL,
+                                                   const float* __restrict__ cD, int H, int W,
+                                                   PhysF64 P, double* __restrict__ grid7,
+                                                   double* __restrict__ temps,
+                                                   double* __restrict__ betas,
+                                                   double* __restrict__ growth,
+                                                   double* __restrict__ teff) {
+    const int b = blockIdx.y;
+    const int cell = blockIdx.x * 256 + threadIdx.x;
+    if (cell >= H * W) return;
+    const size_t n = (size_t)H * W, woff = (size_t)b * n;
+    const int r = cell / W, c = cell - r * W;
+    double l9[9], d9[9];
+    gather9(pL + woff, H, W, r, c, l9);
+    gather9(pD + woff, H, W, r, c, d9);
+    const CellF64 o = cell_f64(P, l9, d9);
+    if (grid7) {
+        double* g = grid7 + (size_t)b * 7 * n + cell;
+        if (POST) {
+            g[0 * n] = dw_round3_k(P.p - o.nl - o.nd) / 1000.0;
+            g[1 * n] = (double)cL[woff + cell] / 1000.0;
+            g[2 * n] = (double)cD[woff + cell] / 1000.0;
+            g[3 * n] = dw_round3_k(o.T) / 1000.0;
+            g[4 * n] = dw_round3_k(o.Tl) / 1000.0;
+            g[5 * n] = dw_round3_k(o.Td) / 1000.0;
+        } else {
+            g[0 * n] = P.p - l9[4] - d9[4];
+            g[1 * n] = l9[4];
+            g[2 * n] = d9[4];
+            g[3 * n] = o.T;
+            g[4 * n] = o.Tl;
+            g[5 * n] = o.Td;
+        }
+        g[6 * n] = 0.0;
+    }
+    if (temps) {
+        double* t = temps + (size_t)b * 3 * n + cell;
+        t[0] = o.T; t[n] = o.Tl; t[2 * n] = o.Td;
+    }
+    if (betas) {
+        double* t = betas + (size_t)b * 3 * n + cell;
+        t[0] = o.b; t[n] = o.bl; t[2 * n] = o.bd;
+    }
+    if (growth) {
+        double* t = growth + (size_t)b * 2 * n + cell;
+        t[0] = o.gl; t[n] = o.gd;
+    }
+    if (teff) teff[woff + cell] = o.Te;
+}
+
+// ref forward :454-459 — agent states into channel 4 at agent cells, in agent order (last wins)
+__global__ void agents_stamp(double* __restrict__ grid7, const int* __restrict__ idx,
+                             const double* __restrict__ st, int B, int N, int H, int W) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const size_t n = (size_t)H * W;
+    for (int a = 0; a < N; ++a) {
+        const int r = idx[((size_t)b * N + a) * 2], c = idx[((size_t)b * N + a) * 2 + 1];
+        grid7[(size_t)b * 7 * n + 4 * n + (size_t)r * W + c] = st[(size_t)b * N + a];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// observe — ref get_obs (:246-263): [B][N][7][3][3] float64 = the 3x3 wrap-around patch of the
+// 7-channel grid around each agent, times the neighbourhood mask.  One thread per (agent, patch
+// cell); the channel values are re-derived in float64 exactly as `materialise` does, so no
+// 7-channel grid ever exists in HBM.  Channel 4 shows agent states at agent cells (ref :459).
+// ---------------------------------------------------------------------------------------------
+template <typename PrevT, bool POST>
+__global__ void observe(const PrevT* __restrict__ pL, const PrevT* __restrict__ pD,
+                        const float* __restrict__ cL, const float* __restrict__ cD,
+                        const int* __restrict__ idx, const double* __restrict__ st, int B, int N,
+                        int H, int W, PhysF64 P, int mask, double* __restrict__ obs) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= B * N * 9) return;
+    const int k = gid % 9, an = gid / 9;       // patch cell, flat agent id
+    const int b = an / N;
+    double* o7 = obs + (size_t)an * 63 + k;    // channel stride 9
+    if (!((mask >> k) & 1)) {
+#pragma unroll
+        for (int ch = 0; ch < 7; ++ch) o7[ch * 9] = 0.0;
+        return;
+    }
+    const int ar = idx[(size_t)an * 2], ac = idx[(size_t)an * 2 + 1];
+    const int r = (ar + (k / 3 - 1) + H) % H, c = (ac + (k % 3 - 1) + W) % W;
+    const size_t n = (size_t)H * W, woff = (size_t)b * n;
+    double l9[9], d9[9];
+    gather9(pL + woff, H, W, r, c, l9);
+    gather9(pD + woff, H, W, r, c, d9);
+    const CellF64 o = cell_f64(P, l9, d9);
+    double v[7];
+    if (POST) {
+        v[0] = dw_round3_k(P.p - o.nl - o.nd) / 1000.0;
+        v[1] = (double)cL[woff + (size_t)r * W + c] / 1000.0;
+        v[2] = (double)cD[woff + (size_t)r * W + c] / 1000.0;
+        v[3] = dw_round3_k(o.T) / 1000.0;
+        v[4] = dw_round3_k(o.Tl) / 1000.0;
+        v[5] = dw_round3_k(o.Td) / 1000.0;
+    } else {
+        v[0] = P.p - l9[4] - d9[4]; v[1] = l9[4]; v[2] = d9[4];
+        v[3] = o.T; v[4] = o.Tl; v[5] = o.Td;
+    }
+    v[6] = 0.0;
+    if (POST) {   // ref forward :454-459 (reset()'s initial grid carries no agent stamps)
+        for (int a = 0; a < N; ++a) {
+            const int rr = idx[((size_t)b * N + a) * 2], cc = idx[((size_t)b * N + a) * 2 + 1];
+            if (rr == r && cc == c) v[4] = st[(size_t)b * N + a];
+        }
+    }
+#pragma unroll
+    for (int ch = 0; ch < 7; ++ch) o7[ch * 9] = v[ch];
+}
+
+// ---------------------------------------------------------------------------------------------
+// policy_greedy — ref Greedy.__call__ deterministic branch (agents/greedy.py:18-30):
+// food = light + dark of the observation patch; candidates are flat 3x3 indices [3,1,7,5];
+// action = 4 + argmax (or argmin), first extremum wins.  Reads the CURRENT covers directly
+// (ch1+ch2 of the post-step observation are exactly cur/1000).
+// ---------------------------------------------------------------------------------------------
+__global__ void policy_greedy(const float* __restrict__ cL, const float* __restrict__ cD,
+                              const int* __restrict__ idx, int B, int N, int H, int W, int mask,
+                              int argmin, int* __restrict__ action) {
+    const int an = blockIdx.x * blockDim.x + threadIdx.x;
+    if (an >= B * N) return;
+    const int b = an / N;
+    const int ar = idx[(size_t)an * 2], ac = idx[(size_t)an * 2 + 1];
+    const size_t woff = (size_t)b * H * W;
+    const int cand[4] = {3, 1, 7, 5};
+    int best = 0;
+    double bestv = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = cand[i];
+        double v = 0.0;
+        if ((mask >> k) & 1) {
+            const int r = (ar + (k / 3 - 1) + H) % H, c = (ac + (k % 3 - 1) + W) % W;
+            const size_t o = woff + (size_t)r * W + c;
+            v = (double)cL[o] / 1000.0 + (double)cD[o] / 1000.0;
+        }
+        if (i == 0 || (argmin ? v < bestv : v > bestv)) { best = i; bestv = v; }
+    }
+    action[an] = 4 + best;
+}
+
+// lifespan counters (ref notebooks/greedy_longevity_abatement.ipynb cell 2:46-52)
+__global__ void lifespan_accumulate(const StatsDev* __restrict__ stats, const double* __restrict__ st,
+                                    int B, int N, unsigned int thr, int* __restrict__ done_at,
+                                    int* __restrict__ agents_done_at, int* __restrict__ n_alive) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B) {
+        const int alive = stats[i].max_k > thr ? 1 : 0;      // grid_done = max <= 0.005
+        done_at[i] += alive;
+        if (alive) atomicAdd(n_alive, 1);
+    }
+    if (i < B * N) {
+        const double s = st[i];
+        const double r = s * (s > 0.0 ? 1.0 : 0.0);
+        agents_done_at[i] += (r < 0.1) ? 0 : 1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// init_random — ref initialize_grid :287-302 / initialize_agents :175-179 with Philox4x32-10.
+// counter = (cell lo, cell hi, world lo, world hi), key = seed.  One call per cell gives the four
+// uniforms (U1_dark, U2_dark, U1_light, U2_light); the reference draws dark first.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void init_random_cells(float* __restrict__ L, float* __restrict__ D,
+                                                         int H, int W, long long world_offset,
+                                                         unsigned long long seed, float light_prop,
+                                                         float dark_prop, float ial, float iad) {
+    const int b = blockIdx.y;
+    const int cell = blockIdx.x * 256 + threadIdx.x;
+    if (cell >= H * W) return;
+    const unsigned long long world = (unsigned long long)(world_offset + b);
+    uint32_t r[4];
+    philox4x32_10((uint32_t)cell, 0u, (uint32_t)world, (uint32_t)(world >> 32), (uint32_t)seed,
+                  (uint32_t)(seed >> 32), r);
+    const float d = (u01(r[0]) < dark_prop) ? iad * u01(r[1]) : 0.f;
+    const float l = (u01(r[2]) < light_prop) ? ial * u01(r[3]) : 0.f;
+    const size_t o = (size_t)b * H * W + cell;
+    L[o] = l * 1000.f;
+    D[o] = d * 1000.f;
+}
+
+__global__ void init_random_agents(int* __restrict__ idx, double* __restrict__ st, int B, int N, int H,
+                                   int W, long long world_offset, unsigned long long seed) {
+    const int an = blockIdx.x * blockDim.x + threadIdx.x;
+    if (an >= B * N) return;
+    const int b = an / N, a = an - b * N;
+    const unsigned long long world = (unsigned long long)(world_offset + b);
+    uint32_t r[4];
+    philox4x32_10((uint32_t)a, 0x80000000u, (uint32_t)world, (uint32_t)(world >> 32), (uint32_t)seed,
+                  (uint32_t)(seed >> 32), r);
+    idx[(size_t)an * 2 + 0] = (int)(((unsigned long long)r[0] * (unsigned)H) >> 32);
+    idx[(size_t)an * 2 + 1] = (int)(((unsigned long long)r[1] * (unsigned)W) >> 32);
+    st[an] = 1.0;
+}
+
+// plane conversions
+__global__ void f64_to_permille(const double* __restrict__ in, float* __restrict__ out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (float)(in[i] * 1000.0);
+}
+__global__ void f32nat_to_permille(const float* __restrict__ in, float* __restrict__ out, size_t n,
+                                   int quantise) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const float k = in[i] * 1000.f;
+        out[i] = quantise ? __builtin_rintf(k) : k;
+    }
+}
+__global__ void permille_to_f64(const float* __restrict__ in, double* __restrict__ out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (double)in[i] / 1000.0;
+}
+
+// stats of an arbitrary state (used after uploads / init so that dw_reduce is always valid)
+template <typename T>
+__global__ __launch_bounds__(256) void stats_only(const T* __restrict__ L, const T* __restrict__ D,
+                                                  int H, int W, StatsDev* __restrict__ stats) {
+    const int b = blockIdx.y;
+    const int cell = blockIdx.x * 256 + threadIdx.x;
+    float kl = 0.f, kd = 0.f;
+    if (cell < H * W) {
+        kl = to_permille(L[(size_t)b * H * W + cell]);
+        kd = to_permille(D[(size_t)b * H * W + cell]);
+    }
+    const float m = wave_max(fmaxf(kl, kd));
+    const float sl = wave_sum(kl), sd = wave_sum(kd);
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(&stats[b].max_k, (unsigned int)ceilf(m));
+        atomicAdd(&stats[b].sum_l, (unsigned long long)(sl + 0.5f));
+        atomicAdd(&stats[b].sum_d, (unsigned long long)(sd + 0.5f));
+    }
+}
+
+}  // namespace dw

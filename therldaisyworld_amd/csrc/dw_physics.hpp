@@ -1,0 +1,197 @@
+// dw_physics.hpp — per-cell arithmetic of the RLDaisyWorld physics pass for gfx950.
+//
+// Two evaluations of the same map (reference
+// daisy/daisy_world_rl.py:340-461):
+//
+//   cell_f64  float64, staged like the reference (albedo -> temperature -> growth-rate ->
+//             growth -> clip).  Used by the DW_PRECISION_F64 kernels, by the materialise /
+//             observation kernels, and as the tie "fix-up" of the exact mode.
+//   growth_f32 float32, the fused algebra of the hot kernel, working in PER-MILLE units so that
+//             every stencil sum of a quantised state is an exact small integer.
+//
+// Units: the device planes hold k = 1000 * cover.  The reference quantises its state with
+// np.round(., 3) (daisy_world_rl.py:452), so after any step k is an integer in [0, 1000].
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dw {
+
+// ---------------------------------------------------------------------------------------------
+// float64 constants (host fills; passed to kernels by value)
+// ---------------------------------------------------------------------------------------------
+struct PhysF64 {
+    double p, g, S, sigma, gamma, q, q2, dt;
+    double ab, al, ad, To;       // albedo bare/light/dark, optimal temperature
+    double L;                    // luminosity of this pass
+    double w0, w1, w2;           // daisy kernel centre / edge / corner (ref :270-273)
+};
+
+// everything the reference's forward() derives for one cell
+struct CellF64 {
+    double nl, nd;               // clip(cover + dt*growth, 0, 1), NOT yet rounded (ref :449)
+    double T, Tl, Td, Te;        // temp, temp_light, temp_dark, temp_effective (ref :404-413)
+    double b, bl, bd;            // beta, beta_l, beta_d (ref :342-344)
+    double gl, gd;               // growth (ref :366-367)
+};
+
+__host__ __device__ inline double dw_root4(double x) { return sqrt(sqrt(x)); }
+__host__ __device__ inline double dw_pow4(double x) { double s = x * x; return s * s; }
+
+// np.round(x, 3) = rint(x * 1000) / 1000, ties to even (ref :452).  Returns the integer k.
+__host__ __device__ inline double dw_round3_k(double x) { return rint(x * 1000.0); }
+
+// l[9], d[9]: the 3x3 neighbourhood in natural units, row-major, index 4 = the cell itself.
+__host__ __device__ inline CellF64 cell_f64(const PhysF64& P, const double* l, const double* d) {
+    CellF64 o;
+    // ref calculate_albedo :377-394 — bare = p - l - d everywhere, adjacent = mean of the 8
+    // Moore neighbours per cover type, weighted by the albedos in the order bare, light, dark.
+    double sb = 0.0, sl = 0.0, sd = 0.0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        if (i == 4) continue;
+        sb += 0.125 * (P.p - l[i] - d[i]);
+        sl += 0.125 * l[i];
+        sd += 0.125 * d[i];
+    }
+    const double bare = P.p - l[4] - d[4];
+    double Al = 0.0, A = 0.0;
+    Al += P.ab * bare; A += P.ab * sb;
+    Al += P.al * l[4]; A += P.al * sl;
+    Al += P.ad * d[4]; A += P.ad * sd;
+    // ref calculate_temperature :396-421
+    o.Te = dw_root4((P.S * P.L * (1.0 - A)) / P.sigma);
+    o.T = dw_root4(P.q * (A - Al) + dw_pow4(o.Te));
+    const double T4 = dw_pow4(o.T);
+    o.Tl = dw_root4(P.q2 * (Al - P.al) + T4);
+    o.Td = dw_root4(P.q2 * (Al - P.ad) + T4);
+    // ref calculate_growth_rate :340-348
+    o.b = 1.0 - P.g * (P.To - o.T) * (P.To - o.T);
+    o.bl = 1.0 - P.g * (P.To - o.Tl) * (P.To - o.Tl);
+    o.bd = 1.0 - P.g * (P.To - o.Td) * (P.To - o.Td);
+    // ref calculate_daisy_density :423-432 (symmetric 3-weight kernel)
+    const double kl = P.w0 * l[4] + P.w1 * (l[1] + l[3] + l[5] + l[7]) + P.w2 * (l[0] + l[2] + l[6] + l[8]);
+    const double kd = P.w0 * d[4] + P.w1 * (d[1] + d[3] + d[5] + d[7]) + P.w2 * (d[0] + d[2] + d[6] + d[8]);
+    // ref calculate_growth :350-375
+    const double kb = P.p - kl - kd;
+    o.gl = kl * (kb * o.bl - P.gamma);
+    o.gd = kd * (kb * o.bd - P.gamma);
+    // ref forward :449
+    double nl = l[4] + P.dt * o.gl, nd = d[4] + P.dt * o.gd;
+    o.nl = nl < 0.0 ? 0.0 : (nl > 1.0 ? 1.0 : nl);
+    o.nd = nd < 0.0 ? 0.0 : (nd > 1.0 ? 1.0 : nd);
+    return o;
+}
+
+// ---------------------------------------------------------------------------------------------
+// float32 fused form
+// ---------------------------------------------------------------------------------------------
+// With li, di the centre values and Sl8, Sd8 the sums over the 8 Moore neighbours (all per-mille),
+// K = S*L/sigma and To4 = To^4, the reference's T_x^4 (x = light, dark) is affine in them:
+//   e_x := T_x^4/To4 - 1 = c0x + a1*Sl8 + a2*Sd8 + a3*li + a4*di
+// (coefficients derived in float64 on the host every step, see derive_f32() in dw_api.hip).
+//
+// Accuracy devices (they are what makes the exact mode's tie bound small):
+//  * every coefficient is split as hi + lo with hi a multiple of 2^-hi_bits chosen so that, for a
+//    quantised state (integer li, di, Sl8, Sd8), every product and partial sum of the "hi" chain is
+//    exactly representable in float32: that chain carries NO rounding error; the "lo" chain is
+//    ~2^-12 times smaller, so its roundings are negligible.  e_x then has one rounding (u*|e_x|).
+//  * the fourth root is taken on u = 1 + e as y = sqrt(sqrt(u)), but the deviation from the
+//    optimum temperature is formed as  (T_x - To)/To = y - 1 = e / ((y + 1)(y^2 + 1)),  which keeps
+//    the RELATIVE accuracy of e instead of cancelling two numbers near 1.
+struct PhysF32 {
+    float a1h, a2h, a3h, a4h;    // hi parts of the affine coefficients (per per-mille unit)
+    float a1l, a2l, a3l, a4l;    // lo parts
+    float c0lh, c0ll;            // constant for light, hi / lo
+    float c0dh, c0dl;            // constant for dark
+    float cbeta;                 // g * To^2:  beta = 1 - cbeta * ((T-To)/To)^2
+    float w0, w1, w2;            // daisy kernel weights
+    float p, gamma, dt;
+    // exact-mode tie test (per-mille; om = 1 - beta = cbeta*((T-To)/To)^2 >= 0):
+    //   |frac(gq)| > tie_lo - eA*|gq| - |dt*K|*(eK0 + eK1*om)   =>  re-evaluate in float64
+    float tie_lo, eA, eK0, eK1;
+};
+
+struct GrowthF32 {
+    float gql, gqd;              // per-mille growth dt*K*(kb*beta - gamma) for light, dark
+    float dKl, dKd;              // dt * density (per-mille), used by the tie bound
+    float oml, omd;              // 1 - beta_l, 1 - beta_d (>= 0), used by the tie bound
+};
+
+// El/Cl: sums of the 4 edge / 4 corner neighbours of light; Ed/Cd of dark; li/di the centre.
+__device__ __forceinline__ GrowthF32 growth_f32(const PhysF32& P, float li, float di, float El,
+                                                float Cl, float Ed, float Cd) {
+    const float Sl8 = El + Cl, Sd8 = Ed + Cd;
+    float hi = P.a1h * Sl8;
+    hi = fmaf(P.a2h, Sd8, hi);
+    hi = fmaf(P.a3h, li, hi);
+    hi = fmaf(P.a4h, di, hi);
+    float lo = P.a1l * Sl8;
+    lo = fmaf(P.a2l, Sd8, lo);
+    lo = fmaf(P.a3l, li, lo);
+    lo = fmaf(P.a4l, di, lo);
+    const float el = (hi + P.c0lh) + (lo + P.c0ll);
+    const float ed = (hi + P.c0dh) + (lo + P.c0dl);
+    // light
+    const float sl = __builtin_amdgcn_sqrtf(1.0f + el);
+    const float yl = __builtin_amdgcn_sqrtf(sl);
+    const float dl = el * __builtin_amdgcn_rcpf((yl + 1.0f) * (sl + 1.0f));
+    const float oml = (P.cbeta * dl) * dl;
+    const float bl = 1.0f - oml;
+    // dark
+    const float sd = __builtin_amdgcn_sqrtf(1.0f + ed);
+    const float yd = __builtin_amdgcn_sqrtf(sd);
+    const float dd = ed * __builtin_amdgcn_rcpf((yd + 1.0f) * (sd + 1.0f));
+    const float omd = (P.cbeta * dd) * dd;
+    const float bd = 1.0f - omd;
+    // densities (per-mille) and bare fraction (natural)
+    const float Kl = fmaf(P.w2, Cl, fmaf(P.w1, El, P.w0 * li));
+    const float Kd = fmaf(P.w2, Cd, fmaf(P.w1, Ed, P.w0 * di));
+    const float kb = fmaf(-(Kl + Kd), 0.001f, P.p);
+    GrowthF32 o;
+    o.oml = oml;
+    o.omd = omd;
+    o.dKl = P.dt * Kl;
+    o.dKd = P.dt * Kd;
+    o.gql = o.dKl * fmaf(kb, bl, -P.gamma);
+    o.gqd = o.dKd * fmaf(kb, bd, -P.gamma);
+    return o;
+}
+
+// FAST finaliser: k' = rint(clip(k + gq, 0, 1000)) — valid for any (also un-quantised) input.
+__device__ __forceinline__ float finish_fast(float k, float gq) {
+    return __builtin_rintf(fminf(fmaxf(k + gq, 0.0f), 1000.0f));
+}
+
+// EXACT finaliser for an integer k: rint(k + gq) = k + rint(gq) unless gq is within the float32
+// error bound of a tie, in which case `tie` is raised and the caller re-evaluates in float64.
+__device__ __forceinline__ float finish_exact(const PhysF32& P, float k, float gq, float dK,
+                                              float om, bool& tie) {
+    const float r = __builtin_rintf(gq);
+    const float frac = fabsf(gq - r);                       // exact (Sterbenz)
+    const float thr = fmaf(-fabsf(dK), fmaf(P.eK1, om, P.eK0), fmaf(-P.eA, fabsf(gq), P.tie_lo));
+    tie = frac > thr;
+    return fminf(fmaxf(k + r, 0.0f), 1000.0f);
+}
+
+// Philox4x32-10 (Salmon et al., SC'11) — counter-based RNG for the synthetic initial states.
+__host__ __device__ inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// uniform in [0,1) with 24 random bits (exactly representable in float32)
+__host__ __device__ inline float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
+
+}  // namespace dw

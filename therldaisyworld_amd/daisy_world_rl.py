@@ -1,0 +1,400 @@
+"""Drop-in ``RLDaisyWorld`` whose grid update runs on an MI355X through libdaisyworld_hip.so.
+
+Mirrors the public surface of the reference class (``/root/reference/daisy/daisy_world_rl.py``):
+constructor kwargs (:24-29,:44,:62,:79), the mutable attributes callers assign before ``reset()``
+(``batch_size``, ``n_agents``, albedos, ``min_L``/``max_L``/``ramp_period``, ``agent_gamma``, ``dt``,
+``q2``...), ``reset()`` (:327), ``step(action=None)`` (:475), ``forward(grid)`` (:434),
+``get_obs`` (:246), ``update_agents`` (:181), ``update_L`` (:463), ``set_use_microclimate`` (:85) and
+the config helpers (:94-171), and the attributes callers read (``grid``, ``temp``, ``beta``, ``growth``,
+``dead_temp``, ``agent_indices``, ``agent_states``, ``L``, ``dL``, ``step_count``...).
+
+What stays on the host: the legacy NumPy RNG draws (same global stream, same call order as the
+reference, so the same ``np.random.seed`` gives the same worlds), the scalar luminosity recurrence,
+and bookkeeping.  Everything per-cell or per-agent runs in HIP kernels; there is no CPU compute path,
+and construction fails if the HIP library or a gfx950 device is missing.
+"""
+from __future__ import annotations
+
+import json
+import os
+
+import numpy as np
+
+from . import _ffi
+from .engine import Engine, default_params, mask_bits
+from .helpers import query_kwargs
+from .nn.functional import make_neighborhood
+
+
+class _Mirror:
+    """A host copy of device state handed to the caller, plus a snapshot to detect in-place edits."""
+
+    def __init__(self, array):
+        self.array = array
+        self.snapshot = array.copy()
+
+    def dirty(self):
+        return not np.array_equal(self.array, self.snapshot)
+
+
+class RLDaisyWorld:
+
+    def __init__(self, **kwargs):
+        self.ch = 7
+        self.batch_size = 32                                   # ref :20 (kwarg is ignored there too)
+        self.kr = query_kwargs("kr", 1, **kwargs)
+        self.neighborhood_mode = query_kwargs("neighborhood_mode", "von_neumann", **kwargs)
+        self.neighborhood = make_neighborhood(self.kr, self.neighborhood_mode)
+        self.dim = kwargs["grid_dimension"] if "grid_dimension" in kwargs.keys() else 16
+
+        self.p = 1.00
+        self.g = 0.003265
+        self.S = 1000.0
+        self.sigma = 5.67e-8
+        self.gamma = 0.25
+        self.q = 0.2 * self.S / self.sigma
+        self.use_microclimate = True
+        self.collision_mode = query_kwargs("collision_mode", 0, **kwargs)
+        self.q2 = self.q / 8. if self.use_microclimate else 0.0
+        self.Toptim = 295.5
+        self.dt = 1.0
+        self.ddL = 0.
+        self.agent_gamma = 0.05
+        self.max_L = 1.5
+        self.min_L = 0.75
+        self.initial_L = self.min_L
+        self.ramp_period = kwargs["ramp_period"] if "ramp_period" in kwargs.keys() else 512
+        self.ramp_up_down = False
+        self.albedo_bare = 0.5
+        self.albedo_light = 0.75
+        self.albedo_dark = 0.25
+        self.temp_optimal = 295.5
+        self.food_chain_penalty = 0.5
+        self.initial_al = 0.2
+        self.initial_ad = 0.2
+        self.light_proportion = 0.33
+        self.dark_proportion = 0.33
+        self.n_agents = query_kwargs("n_agents", 4, **kwargs)
+
+        # extensions (unknown to the reference, which ignores unknown kwargs)
+        self.precision = query_kwargs("precision", "exact", **kwargs)   # "exact" | "fast" | "f64"
+        self.device = query_kwargs("device", int(os.environ.get("LOCAL_RANK", "0")), **kwargs)
+        self.world_offset = query_kwargs("world_offset", 0, **kwargs)
+
+        self._engine = None
+        self._shape = None
+        self._grid_m = None          # _Mirror of the materialised 7-channel grid
+        self._idx_m = None           # _Mirror of agent_indices (B,N,2) int64
+        self._st_m = None            # _Mirror of agent_states (B,N,1) float64
+        self._agents_on_device = False
+        self._caches = {}
+        self._cache_src = None       # None -> device state; or (light, dark, L) of a forward(grid) call
+        self._L_pass = self.min_L    # luminosity of the most recent physics pass
+
+        self.initialize_neighborhood()
+        self.initialize_agents()
+        self.reset()
+
+    # ------------------------------------------------------------------------------------------
+    # configuration helpers (ref :85-171) — host-only
+    # ------------------------------------------------------------------------------------------
+    def set_use_microclimate(self, use_microclimate=True):
+        self.use_microclimate = use_microclimate
+        self.q2 = self.q / 8. if self.use_microclimate else 0.0
+
+    _CONFIG_KEYS = ("max_L", "min_L", "initial_L", "ramp_period", "dL", "p", "g", "S", "sigma", "gamma",
+                    "albedo_bare", "albedo_light", "albedo_dark", "temp_optimal", "light_proportion",
+                    "dark_proportion", "initial_al", "initial_ad", "n_agents", "agent_gamma")
+
+    def make_config(self):
+        return {k: getattr(self, k) for k in self._CONFIG_KEYS}
+
+    def save_config(self, filepath=None):
+        if filepath is None:
+            filepath = os.path.join("results", "default_model_config.json")
+        with open(filepath, "w") as f:
+            json.dump(self.make_config(), f)
+
+    def _apply_config(self, config):
+        for k in self._CONFIG_KEYS:
+            setattr(self, k, config[k])
+
+    def load_config(self, filepath=None):
+        if filepath is None:
+            filepath = os.path.join("results", "default_model_config.json")
+        with open(filepath, "r") as f:
+            return json.load(f)
+
+    def restore_config(self, filepath=None):
+        self._apply_config(self.load_config(filepath))
+
+    def initialize_neighborhood(self):
+        """ref :265-283.  The convolution kernels live in the HIP library (dw_api.hip make_f64);
+        the arrays are kept here only because they are public attributes of the reference."""
+        self.n_daisies = 2
+        k = np.ones((1, 1, 3, 3)) * np.exp(-1)
+        k[:, :, 1, 1] = 1.0
+        k[:, :, 0::2, 0::2] = np.exp(-2)
+        self.daisy_kernel = k / k.sum()
+        self.local_albedo_kernel = np.zeros((1, 1, 3, 3))
+        self.local_albedo_kernel[:, :, 1, 1] = 1.0
+        self.adjacent_albedo_kernel = np.ones((1, 1, 3, 3)) / 8.
+        self.adjacent_albedo_kernel[:, :, 1, 1] = 0.
+
+    # ------------------------------------------------------------------------------------------
+    # engine management
+    # ------------------------------------------------------------------------------------------
+    def _params(self):
+        p = default_params(int(self.batch_size), int(self.dim), int(self.dim), int(self.n_agents))
+        p.device = int(self.device)
+        p.precision = _ffi.PRECISION[self.precision]
+        p.obs_mask = mask_bits(self.neighborhood)
+        p.collision_mode = int(self.collision_mode)
+        p.world_offset = int(self.world_offset)
+        for name in ("p", "g", "S", "sigma", "gamma", "q", "q2", "dt", "albedo_bare", "albedo_light",
+                     "albedo_dark", "temp_optimal", "agent_gamma", "food_chain_penalty", "initial_al",
+                     "initial_ad", "light_proportion", "dark_proportion"):
+            setattr(p, name, float(getattr(self, name)))
+        return p
+
+    def _ensure_engine(self):
+        """(Re)create the device handle when the caller changed batch_size / dim / n_agents, and push
+        the current constants (the reference reads its attributes live on every call)."""
+        shape = (int(self.batch_size), int(self.dim), int(self.n_agents), int(self.device))
+        p = self._params()
+        if self._engine is None or shape != self._shape:
+            if self._engine is not None:
+                self._engine.close()
+            self._engine = Engine(p)
+            self._shape = shape
+            self._agents_on_device = False
+        else:
+            self._engine.set_params(p)
+        return self._engine
+
+    def _sync_to_device(self):
+        """Push host-side edits (assignment or in-place mutation of grid / agent arrays)."""
+        eng = self._engine
+        if self._grid_m is not None and self._grid_m.dirty():
+            g = self._grid_m.array
+            eng.upload_state(g[:, 1], g[:, 2])
+            self._grid_m = None
+            self._caches = {}
+        if self._idx_m is not None and (not self._agents_on_device or self._idx_m.dirty() or self._st_m.dirty()):
+            eng.upload_agents(self._idx_m.array, self._st_m.array[..., 0])
+            self._idx_m.snapshot = self._idx_m.array.copy()
+            self._st_m.snapshot = self._st_m.array.copy()
+            self._agents_on_device = True
+
+    def _invalidate(self):
+        self._grid_m = None
+        self._caches = {}
+        self._cache_src = None
+        self._idx_m = None
+        self._st_m = None
+
+    # ------------------------------------------------------------------------------------------
+    # public state attributes
+    # ------------------------------------------------------------------------------------------
+    @property
+    def grid(self):
+        if self._grid_m is None:
+            self._sync_to_device()
+            self._grid_m = _Mirror(self._engine.download_grid(self._L_pass))
+        return self._grid_m.array
+
+    @grid.setter
+    def grid(self, value):
+        value = np.array(value, dtype=np.float64)
+        self._engine.upload_state(value[:, 1], value[:, 2])
+        self._grid_m = None
+        self._caches = {}
+        self._cache_src = None
+
+    def _pull_agents(self):
+        if self._idx_m is None:
+            idx, st = self._engine.download_agents()
+            self._idx_m = _Mirror(idx.astype(np.int64))
+            self._st_m = _Mirror(st[..., None].copy())
+
+    @property
+    def agent_indices(self):
+        self._pull_agents()
+        return self._idx_m.array
+
+    @agent_indices.setter
+    def agent_indices(self, value):
+        self._pull_agents()
+        self._idx_m.array = np.array(value, dtype=np.int64)
+        self._agents_on_device = False
+
+    @property
+    def agent_states(self):
+        self._pull_agents()
+        return self._st_m.array
+
+    @agent_states.setter
+    def agent_states(self, value):
+        self._pull_agents()
+        self._st_m.array = np.array(value, dtype=np.float64)
+        self._agents_on_device = False
+
+    # side-effect caches of the last physics pass (ref :345-347,373,404,415-419)
+    def _cache(self, name):
+        if not self._caches:
+            if self._cache_src is None:
+                self._sync_to_device()
+                t, b, g, e = self._engine.download_caches(self._L_pass)
+            else:
+                light, dark, L = self._cache_src
+                _, t, b, g, e = self._engine.forward(light, dark, L, want_caches=True)
+            self._caches = {"temp": t[:, 0:1], "temp_light": t[:, 1:2], "temp_dark": t[:, 2:3],
+                            "beta": b[:, 0:1], "beta_l": b[:, 1:2], "beta_d": b[:, 2:3], "growth": g,
+                            "temp_effective": e}
+        return self._caches[name]
+
+    temp = property(lambda self: self._cache("temp"))
+    temp_light = property(lambda self: self._cache("temp_light"))
+    temp_dark = property(lambda self: self._cache("temp_dark"))
+    temp_effective = property(lambda self: self._cache("temp_effective"))
+    beta = property(lambda self: self._cache("beta"))
+    beta_l = property(lambda self: self._cache("beta_l"))
+    beta_d = property(lambda self: self._cache("beta_d"))
+    growth = property(lambda self: self._cache("growth"))
+
+    @property
+    def dead_temp(self):
+        """ref :407-408,:416 — temperature of a lifeless planet at the luminosity of the last pass."""
+        return np.array([((self.S * self._L_pass * (1 - self.albedo_bare)) / self.sigma) ** (1 / 4)])
+
+    # ------------------------------------------------------------------------------------------
+    # initialisation (ref :173-179, :285-338): host RNG in the reference's call order
+    # ------------------------------------------------------------------------------------------
+    def initialize_agents(self):
+        idx = np.random.randint(self.dim, size=(self.batch_size, self.n_agents, 2))
+        st = np.ones((self.batch_size, self.n_agents, 1))
+        self._idx_m = _Mirror(idx.astype(np.int64))
+        self._st_m = _Mirror(st)
+        self._agents_on_device = False
+
+    def draw_initial_cover(self):
+        """The RNG half of ref initialize_grid :287-302 (dark drawn first, then light)."""
+        B, d = self.batch_size, self.dim
+        dark_probability = np.random.rand(B, 2, d, d)
+        light_probability = np.random.rand(B, 2, d, d)
+        dark = 1.0 * (dark_probability[:, 0] < self.dark_proportion) * self.initial_ad * dark_probability[:, 1]
+        light = 1.0 * (light_probability[:, 0] < self.light_proportion) * self.initial_al * light_probability[:, 1]
+        return light, dark
+
+    def initialize_grid(self):
+        light, dark = self.draw_initial_cover()
+        eng = self._ensure_engine()
+        eng.upload_state(light, dark)
+        self._L_pass = self.L
+        self._grid_m = None
+        self._caches = {}
+        self._cache_src = None
+
+    def reset(self):
+        self.L = self.min_L
+        self.dL = (self.max_L - self.min_L) / self.ramp_period
+        self.step_count = 0
+        self.initialize_grid()
+        self.initialize_agents()
+        return self.get_obs(self.agent_indices)
+
+    def reset_synthetic(self, seed=0):
+        """Extension: device-side initial state (Philox keyed by seed / global world id / cell) with
+        the distribution of initialize_grid / initialize_agents — for grids too large to draw and
+        upload from the host.  Not stream-compatible with np.random."""
+        self.L = self.min_L
+        self.dL = (self.max_L - self.min_L) / self.ramp_period
+        self.step_count = 0
+        eng = self._ensure_engine()
+        eng.init_random(seed)
+        self._L_pass = self.L
+        self._invalidate()
+        self._agents_on_device = True
+        return None
+
+    # ------------------------------------------------------------------------------------------
+    # the path
+    # ------------------------------------------------------------------------------------------
+    def get_obs(self, agent_indices=None):
+        """ref :246-263."""
+        eng = self._ensure_engine()
+        if agent_indices is not None and self._idx_m is not None and agent_indices is not self._idx_m.array:
+            if not np.array_equal(agent_indices, self._idx_m.array):
+                # observations around caller-supplied positions: temporary upload
+                saved = self._idx_m.array
+                self._idx_m.array = np.array(agent_indices, dtype=np.int64)
+                self._agents_on_device = False
+                self._sync_to_device()
+                obs = eng.get_obs(self._L_pass)
+                self._idx_m.array = saved
+                self._agents_on_device = False
+                return obs
+        self._sync_to_device()
+        return eng.get_obs(self._L_pass)
+
+    def update_agents(self, action):
+        """ref :181-244."""
+        eng = self._ensure_engine()
+        self._sync_to_device()
+        eng.update_agents(action)
+        self._invalidate()
+
+    def forward(self, grid):
+        """ref :434-461 — stateless w.r.t. the covers: evaluates the physics pass on `grid` in float64
+        on the device and returns the new 7-channel grid; like the reference it rewrites channel 0
+        of its argument in place (:381) and refreshes temp/beta/growth."""
+        eng = self._ensure_engine()
+        self._sync_to_device()
+        grid[:, 0] = self.p - grid[:, 1] - grid[:, 2]
+        light = np.ascontiguousarray(grid[:, 1], dtype=np.float64)
+        dark = np.ascontiguousarray(grid[:, 2], dtype=np.float64)
+        new_grid = eng.forward(light, dark, self.L)
+        self._L_pass = self.L
+        self._caches = {}
+        self._cache_src = (light, dark, self.L)
+        return new_grid
+
+    def update_L(self, L):
+        """ref :463-473 (host float64 scalar)."""
+        self.step_count += 1
+        if self.ramp_up_down and self.step_count % self.ramp_period == 0:
+            self.dL *= -1
+            self.min_L -= self.ddL
+            self.max_L += self.ddL
+        L += self.dL
+        return max([min([L, self.max_L]), self.min_L])
+
+    def step(self, action=None):
+        """ref :475-497."""
+        eng = self._ensure_engine()
+        self._sync_to_device()
+        if action is None and self.n_agents:
+            action = np.zeros((self.batch_size, self.n_agents, 1))
+        eng.step(self.L, action)
+        self._L_pass = self.L
+        self._invalidate()
+        obs = eng.get_obs(self._L_pass)
+        if self.n_agents:
+            reward, _ = eng.reward_done()
+        else:
+            s = eng.reduce()
+            reward = np.stack([s["sum_light_k"] > 0, s["sum_dark_k"] > 0], axis=-1)
+        reward = reward * (reward > 0)
+        done = reward < 0.1
+        info = {}
+        self.L = self.update_L(self.L)
+        return obs, reward, done, info
+
+    def __call__(self, grid):
+        pass
+
+    # extension: release the device handle explicitly
+    def close(self):
+        if self._engine is not None:
+            self._engine.close()
+            self._engine = None

@@ -1,0 +1,237 @@
+"""`Engine`: a thin NumPy-in / NumPy-out object over the C ABI (include/daisyworld_hip.h).
+
+It owns one ``dw_handle`` (one HIP device, one stream).  All compute happens in the HIP library; this
+class only marshals arrays and raises ``DaisyHipError`` on any failure.  The gym-style drop-in
+``therldaisyworld_amd.RLDaisyWorld`` is built on it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import DwParams, DwWorldStats, check
+
+VON_NEUMANN_MASK = 0x0BA
+MOORE_MASK = 0x1FF
+
+
+def mask_bits(neighborhood: np.ndarray) -> int:
+    """3x3 0/1 array -> the 9-bit row-major mask of dw_params.obs_mask."""
+    nb = np.asarray(neighborhood)
+    if nb.shape != (3, 3):
+        raise ValueError("only kr=1 (3x3) observation neighbourhoods are supported "
+                         "(the reference hard-codes 3, daisy_world_rl.py:258)")
+    bits = 0
+    for i, v in enumerate(nb.ravel()):
+        if v:
+            bits |= 1 << i
+    return bits
+
+
+def default_params(batch, height, width, n_agents) -> DwParams:
+    p = DwParams()
+    check(_ffi.load().dw_default_params(C.byref(p), batch, height, width, n_agents))
+    return p
+
+
+class Engine:
+    def __init__(self, params: DwParams):
+        self._lib = _ffi.load()
+        self._h = C.c_void_p()
+        self.params = DwParams()
+        C.memmove(C.byref(self.params), C.byref(params), C.sizeof(DwParams))
+        check(self._lib.dw_create(C.byref(self.params), C.byref(self._h)))
+        p = self.params
+        self.B, self.H, self.W, self.N = p.batch, p.height, p.width, p.n_agents
+
+    # -- life cycle ---------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.dw_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_params(self, params: DwParams):
+        check(self._lib.dw_set_params(self._h, C.byref(params)))
+        C.memmove(C.byref(self.params), C.byref(params), C.sizeof(DwParams))
+
+    # -- state --------------------------------------------------------------------------------
+    def _plane(self, a, dtype):
+        a = np.ascontiguousarray(a, dtype=dtype)
+        if a.shape != (self.B, self.H, self.W):
+            raise ValueError(f"plane shape {a.shape} != {(self.B, self.H, self.W)}")
+        return a
+
+    def upload_state(self, light, dark):
+        light, dark = self._plane(light, np.float64), self._plane(dark, np.float64)
+        check(self._lib.dw_upload_state_f64(self._h, _ffi.ptr_d(light), _ffi.ptr_d(dark)))
+
+    def upload_state_f32(self, light, dark, quantised=False):
+        light, dark = self._plane(light, np.float32), self._plane(dark, np.float32)
+        check(self._lib.dw_upload_state_f32(self._h, _ffi.ptr_f(light), _ffi.ptr_f(dark), int(quantised)))
+
+    def upload_agents(self, indices, states):
+        idx = np.ascontiguousarray(indices, dtype=np.int32).reshape(self.B, self.N, 2)
+        st = np.ascontiguousarray(states, dtype=np.float64).reshape(self.B, self.N)
+        check(self._lib.dw_upload_agents(self._h, _ffi.ptr_i(idx), _ffi.ptr_d(st)))
+
+    def download_agents(self):
+        idx = np.empty((self.B, self.N, 2), dtype=np.int32)
+        st = np.empty((self.B, self.N), dtype=np.float64)
+        check(self._lib.dw_download_agents(self._h, _ffi.ptr_i(idx), _ffi.ptr_d(st)))
+        return idx, st
+
+    def init_random(self, seed: int):
+        check(self._lib.dw_init_random(self._h, C.c_uint64(seed & (2 ** 64 - 1))))
+
+    def download_planes(self, which=_ffi.STATE_CURRENT):
+        light = np.empty((self.B, self.H, self.W))
+        dark = np.empty((self.B, self.H, self.W))
+        check(self._lib.dw_download_planes(self._h, which, _ffi.ptr_d(light), _ffi.ptr_d(dark)))
+        return light, dark
+
+    def download_grid(self, L_init=0.75):
+        grid = np.empty((self.B, 7, self.H, self.W))
+        check(self._lib.dw_download_grid(self._h, float(L_init), _ffi.ptr_d(grid)))
+        return grid
+
+    def download_caches(self, L, temps=True, betas=True, growth=True, temp_effective=True):
+        B, H, W = self.B, self.H, self.W
+        t = np.empty((B, 3, H, W)) if temps else None
+        b = np.empty((B, 3, H, W)) if betas else None
+        g = np.empty((B, 2, H, W)) if growth else None
+        e = np.empty((B, 1, H, W)) if temp_effective else None
+        check(self._lib.dw_download_caches(self._h, float(L), _ffi.ptr_d(t), _ffi.ptr_d(b), _ffi.ptr_d(g),
+                                           _ffi.ptr_d(e)))
+        return t, b, g, e
+
+    # -- hot path -----------------------------------------------------------------------------
+    @staticmethod
+    def _actions(action):
+        """(b, n, 1) or (b, n) integer-valued array -> C-contiguous int32 (b, n)."""
+        a = np.asarray(action)
+        if a.ndim == 3:
+            a = a[..., 0]
+        if a.ndim != 2:
+            raise ValueError(f"action must have shape (b, n, 1); got {np.shape(action)}")
+        if not np.issubdtype(a.dtype, np.integer):
+            ai = np.rint(a)
+            if not np.array_equal(ai, a):
+                raise ValueError("non-integral action codes are not supported")
+            a = ai
+        return np.ascontiguousarray(a, dtype=np.int32)
+
+    def step(self, L, action=None):
+        if action is None:
+            check(self._lib.dw_step(self._h, None, 0, 0, float(L)))
+        else:
+            a = self._actions(action)
+            check(self._lib.dw_step(self._h, _ffi.ptr_i(a), a.shape[0], a.shape[1], float(L)))
+
+    def step_device_actions(self, L):
+        check(self._lib.dw_step_device_actions(self._h, float(L)))
+
+    def step_n(self, nsteps, L, dL, min_L, max_L, use_device_actions=False):
+        Lc = C.c_double(float(L))
+        check(self._lib.dw_step_n(self._h, int(nsteps), C.byref(Lc), float(dL), float(min_L), float(max_L),
+                                  int(bool(use_device_actions))))
+        return Lc.value
+
+    def update_agents(self, action):
+        a = self._actions(action)
+        check(self._lib.dw_update_agents(self._h, _ffi.ptr_i(a), a.shape[0], a.shape[1]))
+
+    def upload_actions(self, action):
+        a = self._actions(action)
+        if a.shape != (self.B, self.N):
+            raise ValueError(f"device action buffer needs shape {(self.B, self.N)}")
+        check(self._lib.dw_upload_actions(self._h, _ffi.ptr_i(a)))
+
+    def download_actions(self):
+        a = np.empty((self.B, self.N), dtype=np.int32)
+        check(self._lib.dw_download_actions(self._h, _ffi.ptr_i(a)))
+        return a
+
+    def forward(self, light, dark, L, want_caches=False):
+        light, dark = self._plane(light, np.float64), self._plane(dark, np.float64)
+        B, H, W = self.B, self.H, self.W
+        grid = np.empty((B, 7, H, W))
+        if want_caches:
+            t, b, g, e = np.empty((B, 3, H, W)), np.empty((B, 3, H, W)), np.empty((B, 2, H, W)), np.empty((B, 1, H, W))
+        else:
+            t = b = g = e = None
+        check(self._lib.dw_forward_f64(self._h, _ffi.ptr_d(light), _ffi.ptr_d(dark), float(L), _ffi.ptr_d(grid),
+                                       _ffi.ptr_d(t), _ffi.ptr_d(b), _ffi.ptr_d(g), _ffi.ptr_d(e)))
+        return (grid, t, b, g, e) if want_caches else grid
+
+    def get_obs(self, L_init=0.75):
+        obs = np.zeros((self.B, self.N, 7, 3, 3))
+        if self.B * self.N:
+            check(self._lib.dw_get_obs(self._h, float(L_init), _ffi.ptr_d(obs)))
+        return obs
+
+    def reward_done(self):
+        reward = np.zeros((self.B, self.N, 1))
+        done = np.zeros((self.B, self.N, 1), dtype=np.uint8)
+        if self.B * self.N:
+            check(self._lib.dw_get_reward_done(self._h, _ffi.ptr_d(reward), _ffi.ptr_u8(done)))
+        return reward, done.astype(bool)
+
+    def reduce(self):
+        out = np.zeros(self.B, dtype=_ffi.STATS_DTYPE)
+        check(self._lib.dw_reduce(self._h, out.ctypes.data_as(C.POINTER(DwWorldStats))))
+        return out
+
+    def policy_greedy(self, argmin=False):
+        check(self._lib.dw_policy_greedy(self._h, _ffi.POLICY_ARGMIN if argmin else _ffi.POLICY_ARGMAX))
+
+    def lifespan_reset(self):
+        check(self._lib.dw_lifespan_reset(self._h))
+
+    def lifespan_accumulate(self, threshold_k=5):
+        check(self._lib.dw_lifespan_accumulate(self._h, int(threshold_k)))
+
+    def lifespan_download(self):
+        done_at = np.zeros(self.B, dtype=np.int32)
+        agents = np.zeros((self.B, self.N, 1), dtype=np.int32)
+        alive = C.c_int32(0)
+        check(self._lib.dw_lifespan_download(self._h, _ffi.ptr_i(done_at), _ffi.ptr_i(agents) if self.N else None,
+                                             C.byref(alive)))
+        return done_at, agents, alive.value
+
+    # -- plumbing -----------------------------------------------------------------------------
+    def set_stream(self, hip_stream_ptr: int):
+        check(self._lib.dw_set_stream(self._h, C.c_void_p(hip_stream_ptr)))
+
+    def sync(self):
+        check(self._lib.dw_sync(self._h))
+
+    def timer_start(self):
+        check(self._lib.dw_timer_start(self._h))
+
+    def timer_stop(self) -> float:
+        ms = C.c_float(0)
+        check(self._lib.dw_timer_stop(self._h, C.byref(ms)))
+        return ms.value
+
+    def device_planes(self, which=_ffi.STATE_CURRENT):
+        lp, dp = C.c_void_p(), C.c_void_p()
+        check(self._lib.dw_device_planes(self._h, which, C.byref(lp), C.byref(dp)))
+        return lp.value, dp.value
+
+    def kernel_info(self) -> str:
+        buf = C.create_string_buffer(512)
+        check(self._lib.dw_kernel_info(self._h, buf, 512))
+        return buf.value.decode()
+
+    def last_fixup_count(self) -> int:
+        v = C.c_uint64(0)
+        check(self._lib.dw_last_fixup_count(self._h, C.byref(v)))
+        return int(v.value)
