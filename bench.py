@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""bench.py — cell-updates/s of the fused RLDaisyWorld step on MI355X, with roofline and CPU baseline.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c5|c1|target] [--precision exact|fast]
+
+A "step" is one pass of the hot path (ref RLDaisyWorld.step, daisy_world_rl.py:475-497) over the
+whole batch of synthetic worlds: update_agents (if the workload has agents) + the fused
+stencil/reaction kernel + per-world reductions.  State is resident in HBM before the timed region
+(device-side Philox initial state).  One process per GPU; worlds are independent, so
+ranks share nothing in the data path (weak scaling: every rank steps its own `worlds` worlds) and
+RCCL is used only for the barrier / max-over-ranks timing and a final gather of per-world statistics.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     algorithmic 16 B per cell-update (float32 light+dark read once, written once) x the
+               cells of one launch / the step kernel's average launch duration measured here with HIP
+               events on the kernel's own stream, against the 8 TB/s HBM3E peak.
+  cpu_baseline the oracle's C restatement (oracle/daisy_oracle.c, "port") timed on this host's cores
+               on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import glob
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+BYTES_PER_CELL_UPDATE = 16       # 2 x float32 read + 2 x float32 written
+
+WORKLOADS = {
+    # name: (worlds per GPU, grid, agents per world, description)
+    "c1": (1, 64, 0, "BASELINE configs[0]: 1 world, 64x64, no agent (the reference's CPU-runnable case)"),
+    "c2": (1024, 256, 0, "BASELINE configs[1]: 1024 worlds, 256x256, no agent, ramped luminosity"),
+    "c3": (256, 1024, 1, "BASELINE configs[2]: 256 worlds, 1024x1024, 1 greedy agent per world"),
+    "c5": (8, 8192, 16, "BASELINE configs[4] per-GPU shard: 8 worlds, 8192x8192, 16 mixed-policy agents"),
+    "target": (256, 4096, 0, "north-star grid: 4096x4096 worlds, no agent (worlds sized to fit beside other tenants)"),
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--worlds", type=int, default=0, help="override worlds per GPU")
+    ap.add_argument("--precision", default="exact", choices=["exact", "fast", "f64"])
+    ap.add_argument("--seed", type=int, default=42)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(grid: int, params_obj, budget_s: float = 12.0):
+    """Time the oracle's C restatement on this host: all cores (OpenMP over worlds) and one thread."""
+    from oracle import c_oracle
+    c_oracle.build()
+    cores = max(1, min(c_oracle.max_threads(), len(os.sched_getaffinity(0))))
+    g = min(grid, 256)                               # bounded sample of the workload's grid
+    worlds = 2 * cores
+    rng = np.random.RandomState(0)
+
+    def fresh():
+        light = (rng.rand(worlds, g, g) < 0.33) * 0.2 * rng.rand(worlds, g, g)
+        dark = (rng.rand(worlds, g, g) < 0.33) * 0.2 * rng.rand(worlds, g, g)
+        return np.ascontiguousarray(light), np.ascontiguousarray(dark)
+
+    c_oracle.set_threads(cores)
+    light, dark = fresh()
+    c_oracle.step_n(light, dark, 0.75, 0.75 / 512, 1)                      # warm-up (thread pool, pages)
+    t0 = time.perf_counter()
+    c_oracle.step_n(light, dark, 0.75, 0.75 / 512, 2)
+    per_step = (time.perf_counter() - t0) / 2
+    steps = int(max(4, min(200, budget_s * 0.7 / max(per_step, 1e-6))))
+    light, dark = fresh()
+    t0 = time.perf_counter()
+    c_oracle.step_n(light, dark, 0.75, 0.75 / 512, steps)
+    dt = time.perf_counter() - t0
+    rate_all = worlds * g * g * steps / dt
+    # single thread on a smaller slice
+    c_oracle.set_threads(1)
+    l1, d1 = light[:1].copy(), dark[:1].copy()
+    s1 = max(2, steps // 4)
+    t0 = time.perf_counter()
+    c_oracle.step_n(l1, d1, 0.75, 0.75 / 512, s1)
+    rate_1 = g * g * s1 / (time.perf_counter() - t0)
+    c_oracle.set_threads(cores)
+    return {
+        "value": rate_all, "unit": "cell-updates/s", "cores": cores, "kind": "port",
+        "sample": f"oracle/daisy_oracle.c (float64, reference staging), {worlds} worlds x {g}x{g} x {steps} steps, "
+                  f"OpenMP over worlds on {cores} threads; single thread: {rate_1:.3e} cell-updates/s",
+        "single_thread_value": rate_1,
+    }
+
+
+def load_traffic(workload: str, precision: str):
+    """HBM bytes per launch from the PMC profile of the same command, if one has been committed
+    under profiles/ (collected per the guide: separate --pmc passes, FETCH_SIZE x2 on gfx950)."""
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_*.json"))):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        if d.get("workload") == workload and d.get("precision") == precision:
+            best = d
+    return None if best is None else best.get("hbm_bytes_per_launch")
+
+
+def main():
+    args = parse()
+    from therldaisyworld_amd import ensemble
+    rank, local_rank, world = ensemble.rank_info()
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    n_gpus = world
+
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = ensemble.init_process_group("nccl") if world > 1 else None
+
+    import therldaisyworld_amd as amd
+    from therldaisyworld_amd import _ffi
+
+    B, G, N, desc = WORKLOADS[args.workload]
+    if args.worlds:
+        B = args.worlds
+    p = amd.default_params(B, G, G, N)
+    p.device = local_rank
+    p.precision = _ffi.PRECISION[args.precision]
+    p.world_offset = rank * B                       # global world ids: the ensemble is one sweep
+    eng = amd.Engine(p)
+    eng.init_random(args.seed)
+    min_L, max_L, dL = 0.75, 1.5, 0.75 / 512
+
+    # per-agent policy for the agent workloads: greedy (c3) or greedy/antigreedy/random/half-random by
+    # agent index (c5).  Random actions are drawn on the host and uploaded outside the kernels' way.
+    rng = np.random.RandomState(args.seed + rank)
+
+    def run(nsteps, L):
+        if N == 0:
+            return eng.step_n(nsteps, L, dL, min_L, max_L)
+        for _ in range(nsteps):
+            if args.workload == "c5":
+                eng.policy_greedy(argmin=False)
+                a = eng.download_actions()
+                eng.policy_greedy(argmin=True)
+                a[:, 4:8] = eng.download_actions()[:, 4:8]
+                a[:, 8:12] = rng.randint(9, size=(B, 4))
+                half = rng.rand() > 0.5
+                if not half:
+                    a[:, 12:16] = rng.randint(9, size=(B, 4))
+                eng.upload_actions(a)
+            else:
+                eng.policy_greedy(argmin=False)
+            eng.step_device_actions(L)
+            L = min(max(L + dL, min_L), max_L)
+        return L
+
+    L = run(args.warmup, min_L)
+    eng.sync()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    eng.timer_start()
+    L = run(args.steps, L)
+    ev_ms = eng.timer_stop()                        # HIP events on the kernel's stream (synchronises)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed = ensemble.max_over_ranks(elapsed)
+    ev_ms = ensemble.max_over_ranks(ev_ms)
+
+    cells = B * G * G
+    value = cells * args.steps * n_gpus / elapsed
+    kernel_ms = ev_ms / args.steps
+    achieved = BYTES_PER_CELL_UPDATE * cells / (kernel_ms * 1e-3) / 1e9
+    stats = eng.reduce()
+    fixups = eng.last_fixup_count()
+    all_stats = ensemble.gather_per_world(stats) if dist is not None else stats   # end-of-run gather (RCCL)
+    info = eng.kernel_info()
+
+    out = {
+        "metric": "cell-updates/sec (grid x batch), fused stencil+growth step",
+        "value": value,
+        "unit": "cell-updates/s",
+        "n_gpus": n_gpus,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32" if args.precision != "f64" else "f64",
+        "data": "synthetic (device Philox initial state with the distribution of initialize_grid; ramped luminosity)",
+        "config": {"workload": f"{args.workload}: {desc}", "worlds_per_gpu": B, "grid": [G, G], "agents_per_world": N,
+                   "precision": args.precision, "kernel": info, "total_worlds": int(all_stats.shape[0]),
+                   "parallelism": f"ensemble shard x{n_gpus} (no data-path collective)"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(args.workload, args.precision),
+                     "bytes_per_cell_update": BYTES_PER_CELL_UPDATE, "cells_per_launch": cells,
+                     "kernel_ms": kernel_ms, "f64_fixups_last_step": fixups},
+    }
+    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(G, p)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out))
+    eng.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -68,8 +68,11 @@ struct dw_handle {
     int* action = nullptr;            // [B][N]
     int* action_tmp = nullptr;        // staging for host-supplied (possibly sub-shaped) actions
     bool have_agents = false;
-    StatsDev* stats = nullptr;        // [B]
-    unsigned long long* fixups = nullptr;
+    // per-world reductions, double-buffered: each step kernel accumulates into stats2[1-sp] and
+    // clears stats2[sp] for the step after it, so the step loop needs no memset launches.
+    // Element [B] of each buffer carries the float64 fix-up counter (in sum_l).
+    StatsDev* stats2[2] = {nullptr, nullptr};
+    int sp = 0;                       // buffer holding the CURRENT state's reductions
     int* done_at = nullptr;           // [B]
     int* agents_done_at = nullptr;    // [B][N]
     int* n_alive = nullptr;
@@ -196,7 +199,8 @@ static void select_kernel(dw_handle* h) {
 
 template <int TCQ, int RPT, bool EXACT>
 static int launch_tiled(dw_handle* h, const float* iL, const float* iD, float* oL, float* oD,
-                        const PhysF32& P, const PhysF64& P64) {
+                        const PhysF32& P, const PhysF64& P64, StatsDev* stats,
+                        unsigned long long* fixups, unsigned long long* zero_me, int zero_n) {
     auto kern = step_tiled<TCQ, RPT, EXACT>;
     static bool attr_set = false;   // per instantiation
     if (!attr_set) {
@@ -208,7 +212,7 @@ static int launch_tiled(dw_handle* h, const float* iL, const float* iD, float* o
     const unsigned grid = (unsigned)h->geom.chunk * 8u;
     constexpr size_t lds_bytes = TileCfg<TCQ, RPT>::LDS_BYTES;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, h->stream, iL, iD, oL, oD, h->geom, P, P64,
-                       h->stats, h->fixups);
+                       stats, fixups, zero_me, zero_n);
     HIPCHK(hipGetLastError());
     return DW_OK;
 }
@@ -220,36 +224,40 @@ static int launch_forward(dw_handle* h, double L) {
     const int in = h->cur, out = 1 - h->cur;
     const PhysF32 P = derive_f32(p, L);
     const PhysF64 P64 = make_f64(p, L);
-    HIPCHK(hipMemsetAsync(h->stats, 0, sizeof(StatsDev) * p.batch, h->stream));
-    HIPCHK(hipMemsetAsync(h->fixups, 0, sizeof(unsigned long long), h->stream));
+    StatsDev* stats = h->stats2[1 - h->sp];                       // invariant: all zero
+    unsigned long long* fixups = &stats[p.batch].sum_l;
+    unsigned long long* zero_me = reinterpret_cast<unsigned long long*>(h->stats2[h->sp]);
+    const int zero_n = (p.batch + 1) * (int)(sizeof(StatsDev) / sizeof(unsigned long long));
     const dim3 ggrid((unsigned)((p.height * p.width + 255) / 256), (unsigned)p.batch);
     int prec = p.precision;
     if (prec == DW_PRECISION_EXACT && !h->cur_quantised) prec = DW_PRECISION_F64;  // first step
     if (prec == DW_PRECISION_F64) {
         if (h->f64 == F64_CUR)
             hipLaunchKernelGGL((step_generic<double, 2>), ggrid, dim3(256), 0, h->stream, h->L64, h->D64,
-                               h->L32[out], h->D32[out], p.height, p.width, P, P64, h->stats, h->fixups);
+                               h->L32[out], h->D32[out], p.height, p.width, P, P64, stats, fixups, zero_me, zero_n);
         else
             hipLaunchKernelGGL((step_generic<float, 2>), ggrid, dim3(256), 0, h->stream, h->L32[in],
-                               h->D32[in], h->L32[out], h->D32[out], p.height, p.width, P, P64, h->stats,
-                               h->fixups);
+                               h->D32[in], h->L32[out], h->D32[out], p.height, p.width, P, P64, stats,
+                               fixups, zero_me, zero_n);
         HIPCHK(hipGetLastError());
     } else if (h->tcq == 0) {
         if (prec == DW_PRECISION_EXACT)
             hipLaunchKernelGGL((step_generic<float, 0>), ggrid, dim3(256), 0, h->stream, h->L32[in],
-                               h->D32[in], h->L32[out], h->D32[out], p.height, p.width, P, P64, h->stats,
-                               h->fixups);
+                               h->D32[in], h->L32[out], h->D32[out], p.height, p.width, P, P64, stats,
+                               fixups, zero_me, zero_n);
         else
             hipLaunchKernelGGL((step_generic<float, 1>), ggrid, dim3(256), 0, h->stream, h->L32[in],
-                               h->D32[in], h->L32[out], h->D32[out], p.height, p.width, P, P64, h->stats,
-                               h->fixups);
+                               h->D32[in], h->L32[out], h->D32[out], p.height, p.width, P, P64, stats,
+                               fixups, zero_me, zero_n);
         HIPCHK(hipGetLastError());
     } else {
         const bool ex = prec == DW_PRECISION_EXACT;
         int rc;
 #define DW_TILED(T, R)                                                                              \
-    rc = ex ? launch_tiled<T, R, true>(h, h->L32[in], h->D32[in], h->L32[out], h->D32[out], P, P64)  \
-            : launch_tiled<T, R, false>(h, h->L32[in], h->D32[in], h->L32[out], h->D32[out], P, P64)
+    rc = ex ? launch_tiled<T, R, true>(h, h->L32[in], h->D32[in], h->L32[out], h->D32[out], P, P64,  \
+                                       stats, fixups, zero_me, zero_n)                               \
+            : launch_tiled<T, R, false>(h, h->L32[in], h->D32[in], h->L32[out], h->D32[out], P, P64, \
+                                        stats, fixups, zero_me, zero_n)
         if (h->tcq == 64) { DW_TILED(64, 8); }
         else if (h->tcq == 32) { DW_TILED(32, 4); }
         else { DW_TILED(16, 2); }
@@ -257,6 +265,7 @@ static int launch_forward(dw_handle* h, double L) {
         if (rc != DW_OK) return rc;
     }
     h->cur = out;
+    h->sp = 1 - h->sp;
     h->f64 = (h->f64 == F64_CUR) ? F64_PREV : F64_NONE;
     h->cur_quantised = true;
     h->stepped = true;
@@ -367,11 +376,11 @@ int dw_create(const dw_params* p, dw_handle** out) {
     TRY(hipMalloc(&h->agents_done_at, sizeof(int) * bn));
     TRY(hipMalloc(&h->done_at, sizeof(int) * p->batch));
     TRY(hipMalloc(&h->n_alive, sizeof(int)));
-    TRY(hipMalloc(&h->stats, sizeof(StatsDev) * p->batch));
-    TRY(hipMalloc(&h->fixups, sizeof(unsigned long long)));
+    for (int i = 0; i < 2; ++i) {
+        TRY(hipMalloc(&h->stats2[i], sizeof(StatsDev) * (p->batch + 1)));
+        TRY(hipMemsetAsync(h->stats2[i], 0, sizeof(StatsDev) * (p->batch + 1), h->stream));
+    }
     TRY(hipMemsetAsync(h->action, 0, sizeof(int) * bn, h->stream));
-    TRY(hipMemsetAsync(h->stats, 0, sizeof(StatsDev) * p->batch, h->stream));
-    TRY(hipMemsetAsync(h->fixups, 0, sizeof(unsigned long long), h->stream));
     TRY(hipMemsetAsync(h->done_at, 0, sizeof(int) * p->batch, h->stream));
     TRY(hipMemsetAsync(h->agents_done_at, 0, sizeof(int) * bn, h->stream));
     TRY(hipMemsetAsync(h->n_alive, 0, sizeof(int), h->stream));
@@ -392,7 +401,7 @@ int dw_destroy(dw_handle* h) {
     (void)hipFree(h->idx); (void)hipFree(h->st); (void)hipFree(h->action); (void)hipFree(h->action_tmp);
     (void)hipFree(h->reward_d); (void)hipFree(h->done_d);
     (void)hipFree(h->agents_done_at); (void)hipFree(h->done_at); (void)hipFree(h->n_alive);
-    (void)hipFree(h->stats); (void)hipFree(h->fixups); (void)hipFree(h->scratch);
+    (void)hipFree(h->stats2[0]); (void)hipFree(h->stats2[1]); (void)hipFree(h->scratch);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -423,10 +432,11 @@ int dw_get_params(const dw_handle* h, dw_params* out) {
 
 static int refresh_stats_f32(dw_handle* h) {
     const dw_params& p = h->prm;
-    HIPCHK(hipMemsetAsync(h->stats, 0, sizeof(StatsDev) * p.batch, h->stream));
+    for (int i = 0; i < 2; ++i)
+        HIPCHK(hipMemsetAsync(h->stats2[i], 0, sizeof(StatsDev) * (p.batch + 1), h->stream));
     const dim3 g((unsigned)((p.height * p.width + 255) / 256), (unsigned)p.batch);
     hipLaunchKernelGGL((stats_only<float>), g, dim3(256), 0, h->stream, h->L32[h->cur], h->D32[h->cur],
-                       p.height, p.width, h->stats);
+                       p.height, p.width, h->stats2[h->sp]);
     HIPCHK(hipGetLastError());
     return DW_OK;
 }
@@ -735,11 +745,11 @@ int dw_forward_f64(dw_handle* h, const double* light, const double* dark, double
     const dim3 g((unsigned)((p.height * p.width + 255) / 256), (unsigned)p.batch);
     // the reductions of this side computation must not disturb the handle's per-world stats
     StatsDev* tmp_stats = nullptr;
-    HIPCHK(hipMalloc(&tmp_stats, sizeof(StatsDev) * p.batch + sizeof(unsigned long long)));
-    HIPCHK(hipMemsetAsync(tmp_stats, 0, sizeof(StatsDev) * p.batch + sizeof(unsigned long long), h->stream));
-    unsigned long long* tmp_fix = reinterpret_cast<unsigned long long*>(tmp_stats + p.batch);
+    HIPCHK(hipMalloc(&tmp_stats, sizeof(StatsDev) * (p.batch + 1)));
+    HIPCHK(hipMemsetAsync(tmp_stats, 0, sizeof(StatsDev) * (p.batch + 1), h->stream));
+    unsigned long long* tmp_fix = &tmp_stats[p.batch].sum_l;
     hipLaunchKernelGGL((step_generic<double, 2>), g, dim3(256), 0, h->stream, dL, dD, nL, nD, p.height, p.width, P,
-                       P64, tmp_stats, tmp_fix);
+                       P64, tmp_stats, tmp_fix, (unsigned long long*)nullptr, 0);
     hipLaunchKernelGGL((materialise<double, true>), g, dim3(256), 0, h->stream, dL, dD, nL, nD, p.height, p.width,
                        P64, dG, temps ? d_t : (double*)nullptr, betas ? d_b : (double*)nullptr,
                        growth ? d_g : (double*)nullptr, temp_effective ? d_e : (double*)nullptr);
@@ -821,7 +831,8 @@ int dw_reduce(dw_handle* h, dw_world_stats* per_world) {
     NEED(h->have_state, DW_ESTATE, "no state");
     static_assert(sizeof(dw_world_stats) == sizeof(StatsDev), "stats layout");
     HIPCHK(hipSetDevice(h->prm.device));
-    HIPCHK(hipMemcpyAsync(per_world, h->stats, sizeof(StatsDev) * h->prm.batch, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(per_world, h->stats2[h->sp], sizeof(StatsDev) * h->prm.batch, hipMemcpyDeviceToHost,
+                          h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return DW_OK;
 }
@@ -860,7 +871,7 @@ int dw_lifespan_accumulate(dw_handle* h, uint32_t threshold_k) {
     HIPCHK(hipSetDevice(p.device));
     HIPCHK(hipMemsetAsync(h->n_alive, 0, sizeof(int), h->stream));
     const int n = p.batch * (p.n_agents > 0 ? p.n_agents : 1);
-    hipLaunchKernelGGL(lifespan_accumulate, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->stats, h->st, p.batch,
+    hipLaunchKernelGGL(lifespan_accumulate, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->stats2[h->sp], h->st, p.batch,
                        p.n_agents, threshold_k, h->done_at, h->agents_done_at, h->n_alive);
     HIPCHK(hipGetLastError());
     return DW_OK;
@@ -944,7 +955,7 @@ int dw_last_fixup_count(dw_handle* h, uint64_t* count) {
     NEED(h && count, DW_EINVAL, "null argument");
     HIPCHK(hipSetDevice(h->prm.device));
     unsigned long long v = 0;
-    HIPCHK(hipMemcpyAsync(&v, h->fixups, sizeof(v), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(&v, &h->stats2[h->sp][h->prm.batch].sum_l, sizeof(v), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     *count = v;
     return DW_OK;

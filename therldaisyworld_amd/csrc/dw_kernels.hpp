@@ -76,12 +76,16 @@ __global__ __launch_bounds__(256) void step_generic(const InT* __restrict__ inL,
                                                     float* __restrict__ outD, int H, int W,
                                                     PhysF32 P, PhysF64 P64,
                                                     StatsDev* __restrict__ stats,
-                                                    unsigned long long* __restrict__ fixups) {
+                                                    unsigned long long* __restrict__ fixups,
+                                                    unsigned long long* __restrict__ zero_me,
+                                                    int zero_n) {
     const int b = blockIdx.y;
     const int cell = blockIdx.x * 256 + threadIdx.x;
     const size_t woff = (size_t)b * H * W;
     float kl = 0.f, kd = 0.f;
     bool fixed = false;
+    if (blockIdx.x == 0 && blockIdx.y == 0)      // clear the reduction buffer of the NEXT step
+        for (int i = threadIdx.x; i < zero_n; i += 256) zero_me[i] = 0ull;
     if (cell < H * W) {
         const int r = cell / W, c = cell - r * W;
         const InT* pl = inL + woff;
@@ -219,7 +223,9 @@ __global__ __launch_bounds__(256) void step_tiled(const float* __restrict__ inL,
                                                   float* __restrict__ outL,
                                                   float* __restrict__ outD, Geom G, PhysF32 P,
                                                   PhysF64 P64, StatsDev* __restrict__ stats,
-                                                  unsigned long long* __restrict__ fixups) {
+                                                  unsigned long long* __restrict__ fixups,
+                                                  unsigned long long* __restrict__ zero_me,
+                                                  int zero_n) {
     using C = TileCfg<TCQ, RPT>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ unsigned int s_fix[EXACT ? kMaxFix : 1];
@@ -240,6 +246,8 @@ __global__ __launch_bounds__(256) void step_tiled(const float* __restrict__ inL,
     const size_t woff = (size_t)b * G.H * G.W;
 
     if (tid == 0) { s_nfix = 0; s_max = 0; s_suml = 0; s_sumd = 0; }
+    if (t == 0)                                     // clear the reduction buffer of the NEXT step
+        for (int i = tid; i < zero_n; i += 256) zero_me[i] = 0ull;
 
     // ---- phase 1: stage tile + halo into LDS (all loads issued before the first LDS write) ----
     {
