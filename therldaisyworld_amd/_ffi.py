@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdaisyworld_hip.so")
+LIB_PATH = os.environ.get("DW_LIB", os.path.join(_HERE, "libdaisyworld_hip.so"))   # DW_LIB: tuning builds
 
 DW_ABI_VERSION = 1
 DW_OK, DW_EINVAL, DW_ENODEVICE, DW_ENOMEM, DW_EHIP, DW_ESTATE = 0, -1, -2, -3, -4, -5

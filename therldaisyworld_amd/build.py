@@ -25,6 +25,19 @@ def _stale() -> bool:
     return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
 
 
+TUNING_LIB = os.path.join(HERE, "libdaisyworld_hip_tuning.so")
+
+
+def build_tuning_library(verbose: bool = False) -> str:
+    """-DDW_TUNING build with ablation hooks (tools/kbench.py only; select it with DW_LIB=...)."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    cmd = [hipcc, *FLAGS, "-DDW_TUNING", "-o", TUNING_LIB, *[os.path.join(CSRC, s) for s in SOURCES]]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, cwd=CSRC)
+    return TUNING_LIB
+
+
 def build_library(force: bool = False, verbose: bool = False) -> str:
     """Compile the HIP extension if it is missing or older than its sources.  Returns its path."""
     if not force and not _stale():

@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -71,8 +72,13 @@ struct dw_handle {
     // per-world reductions, double-buffered: each step kernel accumulates into stats2[1-sp] and
     // clears stats2[sp] for the step after it, so the step loop needs no memset launches.
     // Element [B] of each buffer carries the float64 fix-up counter (in sum_l).
+    // Each buffer is one allocation: [(B+1) StatsDev][kNumQueues*16 uint queue counters].
     StatsDev* stats2[2] = {nullptr, nullptr};
+    size_t stats_bytes = 0;           // bytes of one such buffer
     int sp = 0;                       // buffer holding the CURRENT state's reductions
+    uint4* fixq = nullptr;            // exact mode: global near-tie queues [kNumQueues][qcap][3]
+    unsigned int qcap = 0;
+    int* redo_tiles = nullptr;        // exact mode: tiles to recompute whole (queue overflow)
     int* done_at = nullptr;           // [B]
     int* agents_done_at = nullptr;    // [B][N]
     int* n_alive = nullptr;
@@ -94,6 +100,21 @@ static int ensure_scratch(dw_handle* h, size_t bytes) {
     h->scratch_bytes = 0;
     HIPCHK(hipMalloc(&h->scratch, bytes));
     h->scratch_bytes = bytes;
+    return DW_OK;
+}
+
+// near-tie queues of the exact mode: room for 1/64 of all cells (the bound flags ~0.3-0.5 %), at
+// least 2048 entries per queue; 48 bytes per entry, i.e. 0.75 B per cell on top of the 16 B of state
+static int ensure_fixq(dw_handle* h) {
+    const dw_params& p = h->prm;
+    if (h->fixq || p.precision != DW_PRECISION_EXACT || p.width % 4 != 0 || p.width < 64) return DW_OK;
+    size_t per_q = (h->cells / 64 + kNumQueues - 1) / kNumQueues;
+    if (per_q < 2048) per_q = 2048;
+    per_q = (per_q + 255) / 256 * 256;
+    h->qcap = (unsigned int)per_q;
+    HIPCHK(hipMalloc(&h->fixq, sizeof(uint4) * 3 * per_q * kNumQueues));
+    const size_t max_tiles = (size_t)p.batch * ((p.height + 7) / 8) * ((p.width / 4 + 15) / 16);
+    HIPCHK(hipMalloc(&h->redo_tiles, sizeof(int) * max_tiles));
     return DW_OK;
 }
 
@@ -183,7 +204,13 @@ static void select_kernel(dw_handle* h) {
     if (p.precision == DW_PRECISION_F64) return;
     if (p.width % 4 != 0) return;
     const int Wq = p.width / 4;
-    if (Wq >= 64) { h->tcq = 64; h->rpt = 8; }
+    if (Wq >= 64) {
+        h->tcq = 64; h->rpt = 4;
+        if (const char* e = std::getenv("DW_TILE_RPT")) {      // tuning experiments only
+            const int r = std::atoi(e);
+            if (r == 2 || r == 4 || r == 8) h->rpt = r;
+        }
+    }
     else if (Wq >= 32) { h->tcq = 32; h->rpt = 4; }
     else if (Wq >= 16) { h->tcq = 16; h->rpt = 2; }
     else return;   // narrow grids: generic kernel
@@ -200,7 +227,7 @@ static void select_kernel(dw_handle* h) {
 template <int TCQ, int RPT, bool EXACT>
 static int launch_tiled(dw_handle* h, const float* iL, const float* iD, float* oL, float* oD,
                         const PhysF32& P, const PhysF64& P64, StatsDev* stats,
-                        unsigned long long* fixups, unsigned long long* zero_me, int zero_n) {
+                        unsigned long long* fixups, unsigned long long* zero_me, int zero_n, const FixQ& fq) {
     auto kern = step_tiled<TCQ, RPT, EXACT>;
     static bool attr_set = false;   // per instantiation
     if (!attr_set) {
@@ -211,9 +238,18 @@ static int launch_tiled(dw_handle* h, const float* iL, const float* iD, float* o
     }
     const unsigned grid = (unsigned)h->geom.chunk * 8u;
     constexpr size_t lds_bytes = TileCfg<TCQ, RPT>::LDS_BYTES;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, h->stream, iL, iD, oL, oD, h->geom, P, P64,
-                       stats, fixups, zero_me, zero_n);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, h->stream, iL, iD, oL, oD, h->geom, P, stats,
+                       fixups, zero_me, zero_n, fq);
     HIPCHK(hipGetLastError());
+    if (EXACT) {
+        // second kernel of the step: dense float64 re-evaluation of the queued near-tie cells
+        const dim3 g((fq.qcap + 255) / 256, kNumQueues);
+        hipLaunchKernelGGL(fixup_cells, g, dim3(256), 0, h->stream, oL, oD, h->prm.height, h->prm.width, P64, stats, fq);
+        // third: whole tiles whose queue overflowed (normally none: exits immediately)
+        hipLaunchKernelGGL(redo_tiles_f64, dim3(256), dim3(256), 0, h->stream, iL, iD, oL, oD, h->geom,
+                           TileCfg<TCQ, RPT>::TR, TCQ, P64, stats, fq);
+        HIPCHK(hipGetLastError());
+    }
     return DW_OK;
 }
 
@@ -227,10 +263,30 @@ static int launch_forward(dw_handle* h, double L) {
     StatsDev* stats = h->stats2[1 - h->sp];                       // invariant: all zero
     unsigned long long* fixups = &stats[p.batch].sum_l;
     unsigned long long* zero_me = reinterpret_cast<unsigned long long*>(h->stats2[h->sp]);
-    const int zero_n = (p.batch + 1) * (int)(sizeof(StatsDev) / sizeof(unsigned long long));
+    const int zero_n = (int)(h->stats_bytes / sizeof(unsigned long long));
+    FixQ fq;
+    fq.entries = h->fixq;
+    fq.counts = reinterpret_cast<unsigned int*>(stats + p.batch + 1);
+    fq.qcap = h->qcap;
+    fq.redo_tiles = h->redo_tiles;
     const dim3 ggrid((unsigned)((p.height * p.width + 255) / 256), (unsigned)p.batch);
     int prec = p.precision;
     if (prec == DW_PRECISION_EXACT && !h->cur_quantised) prec = DW_PRECISION_F64;  // first step
+#ifdef DW_TUNING
+    if (const char* e = std::getenv("DW_ABLATE")) {
+        if (std::strcmp(e, "copy") == 0) {
+            const size_t n4 = h->cells / 4;
+            hipLaunchKernelGGL(copy_planes, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, h->stream,
+                               reinterpret_cast<const float4*>(h->L32[in]), reinterpret_cast<const float4*>(h->D32[in]),
+                               reinterpret_cast<float4*>(h->L32[out]), reinterpret_cast<float4*>(h->D32[out]), n4);
+            HIPCHK(hipGetLastError());
+            h->cur = out; h->sp = 1 - h->sp; h->stepped = true; h->L_last = L;
+            return DW_OK;
+        }
+        const int v = std::strcmp(e, "nomath") == 0 ? 1 : 0;
+        HIPCHK(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_ablate), &v, sizeof(int), 0, hipMemcpyHostToDevice, h->stream));
+    }
+#endif
     if (prec == DW_PRECISION_F64) {
         if (h->f64 == F64_CUR)
             hipLaunchKernelGGL((step_generic<double, 2>), ggrid, dim3(256), 0, h->stream, h->L64, h->D64,
@@ -255,10 +311,12 @@ static int launch_forward(dw_handle* h, double L) {
         int rc;
 #define DW_TILED(T, R)                                                                              \
     rc = ex ? launch_tiled<T, R, true>(h, h->L32[in], h->D32[in], h->L32[out], h->D32[out], P, P64,  \
-                                       stats, fixups, zero_me, zero_n)                               \
+                                       stats, fixups, zero_me, zero_n, fq)                           \
             : launch_tiled<T, R, false>(h, h->L32[in], h->D32[in], h->L32[out], h->D32[out], P, P64, \
-                                        stats, fixups, zero_me, zero_n)
-        if (h->tcq == 64) { DW_TILED(64, 8); }
+                                        stats, fixups, zero_me, zero_n, fq)
+        if (h->tcq == 64 && h->rpt == 8) { DW_TILED(64, 8); }
+        else if (h->tcq == 64 && h->rpt == 4) { DW_TILED(64, 4); }
+        else if (h->tcq == 64) { DW_TILED(64, 2); }
         else if (h->tcq == 32) { DW_TILED(32, 4); }
         else { DW_TILED(16, 2); }
 #undef DW_TILED
@@ -376,10 +434,12 @@ int dw_create(const dw_params* p, dw_handle** out) {
     TRY(hipMalloc(&h->agents_done_at, sizeof(int) * bn));
     TRY(hipMalloc(&h->done_at, sizeof(int) * p->batch));
     TRY(hipMalloc(&h->n_alive, sizeof(int)));
+    h->stats_bytes = sizeof(StatsDev) * (p->batch + 1) + sizeof(unsigned int) * (kNumQueues + 1) * 16;
     for (int i = 0; i < 2; ++i) {
-        TRY(hipMalloc(&h->stats2[i], sizeof(StatsDev) * (p->batch + 1)));
-        TRY(hipMemsetAsync(h->stats2[i], 0, sizeof(StatsDev) * (p->batch + 1), h->stream));
+        TRY(hipMalloc(&h->stats2[i], h->stats_bytes));
+        TRY(hipMemsetAsync(h->stats2[i], 0, h->stats_bytes, h->stream));
     }
+    if (int qrc = ensure_fixq(h)) return cleanup(qrc);
     TRY(hipMemsetAsync(h->action, 0, sizeof(int) * bn, h->stream));
     TRY(hipMemsetAsync(h->done_at, 0, sizeof(int) * p->batch, h->stream));
     TRY(hipMemsetAsync(h->agents_done_at, 0, sizeof(int) * bn, h->stream));
@@ -401,7 +461,7 @@ int dw_destroy(dw_handle* h) {
     (void)hipFree(h->idx); (void)hipFree(h->st); (void)hipFree(h->action); (void)hipFree(h->action_tmp);
     (void)hipFree(h->reward_d); (void)hipFree(h->done_d);
     (void)hipFree(h->agents_done_at); (void)hipFree(h->done_at); (void)hipFree(h->n_alive);
-    (void)hipFree(h->stats2[0]); (void)hipFree(h->stats2[1]); (void)hipFree(h->scratch);
+    (void)hipFree(h->stats2[0]); (void)hipFree(h->stats2[1]); (void)hipFree(h->scratch); (void)hipFree(h->fixq); (void)hipFree(h->redo_tiles);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -419,7 +479,7 @@ int dw_set_params(dw_handle* h, const dw_params* p) {
          DW_EINVAL, "dw_set_params cannot change shape or device; create a new handle");
     h->prm = *p;
     select_kernel(h);
-    return DW_OK;
+    return ensure_fixq(h);
 }
 
 int dw_get_params(const dw_handle* h, dw_params* out) {
@@ -432,8 +492,7 @@ int dw_get_params(const dw_handle* h, dw_params* out) {
 
 static int refresh_stats_f32(dw_handle* h) {
     const dw_params& p = h->prm;
-    for (int i = 0; i < 2; ++i)
-        HIPCHK(hipMemsetAsync(h->stats2[i], 0, sizeof(StatsDev) * (p.batch + 1), h->stream));
+    for (int i = 0; i < 2; ++i) HIPCHK(hipMemsetAsync(h->stats2[i], 0, h->stats_bytes, h->stream));
     const dim3 g((unsigned)((p.height * p.width + 255) / 256), (unsigned)p.batch);
     hipLaunchKernelGGL((stats_only<float>), g, dim3(256), 0, h->stream, h->L32[h->cur], h->D32[h->cur],
                        p.height, p.width, h->stats2[h->sp]);
