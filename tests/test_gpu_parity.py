@@ -126,7 +126,7 @@ def test_exact_mode_uses_float32_path_and_few_fixups(amd):
     eng.upload_state_f32(light.astype(np.float32), dark.astype(np.float32), quantised=True)
     eng.step(1.0)
     n = eng.last_fixup_count()
-    assert "step_tiled" in eng.kernel_info()
+    assert "step_stream" in eng.kernel_info() or "step_tiled" in eng.kernel_info()
     assert 0 < n < 0.02 * light.size, f"{n} float64 fix-ups for {light.size} cells"
     eng.close()
 

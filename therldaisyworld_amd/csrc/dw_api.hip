@@ -79,6 +79,12 @@ struct dw_handle {
     uint4* fixq = nullptr;            // exact mode: global near-tie queues [kNumQueues][qcap][3]
     unsigned int qcap = 0;
     int* redo_tiles = nullptr;        // exact mode: tiles to recompute whole (queue overflow)
+    // streaming kernel (W >= 256)
+    bool use_stream = false;
+    StripGeom sgeom{};
+    uint4* fixw = nullptr;            // exact mode: per-workgroup near-tie regions [nwg][cap][3]
+    unsigned int* fixw_counts = nullptr;
+    unsigned int wcap = 0;
     int* done_at = nullptr;           // [B]
     int* agents_done_at = nullptr;    // [B][N]
     int* n_alive = nullptr;
@@ -107,7 +113,15 @@ static int ensure_scratch(dw_handle* h, size_t bytes) {
 // least 2048 entries per queue; 48 bytes per entry, i.e. 0.75 B per cell on top of the 16 B of state
 static int ensure_fixq(dw_handle* h) {
     const dw_params& p = h->prm;
-    if (h->fixq || p.precision != DW_PRECISION_EXACT || p.width % 4 != 0 || p.width < 64) return DW_OK;
+    if (p.precision != DW_PRECISION_EXACT) return DW_OK;
+    if (h->use_stream) {
+        if (h->fixw) return DW_OK;
+        h->wcap = (unsigned int)((4 * h->sgeom.SR * 256) / 64 < 256 ? 256 : (4 * h->sgeom.SR * 256) / 64);
+        HIPCHK(hipMalloc(&h->fixw, sizeof(uint4) * 3 * (size_t)h->wcap * h->sgeom.nwg));
+        HIPCHK(hipMalloc(&h->fixw_counts, sizeof(unsigned int) * h->sgeom.nwg));
+        return DW_OK;
+    }
+    if (h->fixq || p.width % 4 != 0 || p.width < 64) return DW_OK;
     size_t per_q = (h->cells / 64 + kNumQueues - 1) / kNumQueues;
     if (per_q < 2048) per_q = 2048;
     per_q = (per_q + 255) / 256 * 256;
@@ -201,9 +215,27 @@ static void select_kernel(dw_handle* h) {
     const dw_params& p = h->prm;
     h->tcq = 0;
     h->rpt = 0;
+    h->use_stream = false;
     if (p.precision == DW_PRECISION_F64) return;
     if (p.width % 4 != 0) return;
     const int Wq = p.width / 4;
+    const char* force = std::getenv("DW_KERNEL");               // "tiled" | "stream": A/B experiments
+    if (p.width >= 256 && !(force && std::strcmp(force, "tiled") == 0)) {
+        h->use_stream = true;
+        StripGeom& g = h->sgeom;
+        g.B = p.batch; g.H = p.height; g.W = p.width;
+        g.SR = p.height < 64 ? p.height : 64;
+        if (const char* e = std::getenv("DW_STRIP_ROWS")) {     // tuning experiments only
+            const int r = std::atoi(e);
+            if (r >= 4 && r <= 64) g.SR = r < p.height ? r : p.height;
+        }
+        g.ncs = (p.width + 255) / 256;
+        g.nrs = (p.height + g.SR - 1) / g.SR;
+        g.nstrips = p.batch * g.nrs * g.ncs;
+        g.nwg = (g.nstrips + 3) / 4;
+        g.chunk = (g.nwg + 7) / 8;
+        return;
+    }
     if (Wq >= 64) {
         h->tcq = 64; h->rpt = 4;
         if (const char* e = std::getenv("DW_TILE_RPT")) {      // tuning experiments only
@@ -296,7 +328,7 @@ static int launch_forward(dw_handle* h, double L) {
                                h->D32[in], h->L32[out], h->D32[out], p.height, p.width, P, P64, stats,
                                fixups, zero_me, zero_n);
         HIPCHK(hipGetLastError());
-    } else if (h->tcq == 0) {
+    } else if (h->tcq == 0 && !h->use_stream) {
         if (prec == DW_PRECISION_EXACT)
             hipLaunchKernelGGL((step_generic<float, 0>), ggrid, dim3(256), 0, h->stream, h->L32[in],
                                h->D32[in], h->L32[out], h->D32[out], p.height, p.width, P, P64, stats,
@@ -306,6 +338,32 @@ static int launch_forward(dw_handle* h, double L) {
                                h->D32[in], h->L32[out], h->D32[out], p.height, p.width, P, P64, stats,
                                fixups, zero_me, zero_n);
         HIPCHK(hipGetLastError());
+    } else if (h->use_stream) {
+        const bool ex = prec == DW_PRECISION_EXACT;
+        const StripGeom& g = h->sgeom;
+        FixW fw;
+        fw.entries = h->fixw; fw.counts = h->fixw_counts; fw.cap = h->wcap;
+        const dim3 grid((unsigned)g.chunk * 8u);
+        const int halo = p.width == 256 ? 0 : (p.width % 256 == 0 ? 1 : 2);
+#define DW_STREAM(K, HL)                                                                                \
+    hipLaunchKernelGGL((K<HL>), grid, dim3(256), 0, h->stream, h->L32[in], h->D32[in], h->L32[out],     \
+                       h->D32[out], g, P, stats, fixups, zero_me, zero_n, fw)
+        if (ex) {
+            if (halo == 0) DW_STREAM(step_stream_exact, 0);
+            else if (halo == 1) DW_STREAM(step_stream_exact, 1);
+            else DW_STREAM(step_stream_exact, 2);
+        } else {
+            if (halo == 0) DW_STREAM(step_stream_fast, 0);
+            else if (halo == 1) DW_STREAM(step_stream_fast, 1);
+            else DW_STREAM(step_stream_fast, 2);
+        }
+#undef DW_STREAM
+        HIPCHK(hipGetLastError());
+        if (ex) {
+            hipLaunchKernelGGL(fixup_stream, dim3((fw.cap + 255) / 256, (unsigned)g.nwg), dim3(256), 0, h->stream,
+                               h->L32[in], h->D32[in], h->L32[out], h->D32[out], g, P64, stats, fw);
+            HIPCHK(hipGetLastError());
+        }
     } else {
         const bool ex = prec == DW_PRECISION_EXACT;
         int rc;
@@ -439,6 +497,7 @@ int dw_create(const dw_params* p, dw_handle** out) {
         TRY(hipMalloc(&h->stats2[i], h->stats_bytes));
         TRY(hipMemsetAsync(h->stats2[i], 0, h->stats_bytes, h->stream));
     }
+    select_kernel(h);
     if (int qrc = ensure_fixq(h)) return cleanup(qrc);
     TRY(hipMemsetAsync(h->action, 0, sizeof(int) * bn, h->stream));
     TRY(hipMemsetAsync(h->done_at, 0, sizeof(int) * p->batch, h->stream));
@@ -461,7 +520,7 @@ int dw_destroy(dw_handle* h) {
     (void)hipFree(h->idx); (void)hipFree(h->st); (void)hipFree(h->action); (void)hipFree(h->action_tmp);
     (void)hipFree(h->reward_d); (void)hipFree(h->done_d);
     (void)hipFree(h->agents_done_at); (void)hipFree(h->done_at); (void)hipFree(h->n_alive);
-    (void)hipFree(h->stats2[0]); (void)hipFree(h->stats2[1]); (void)hipFree(h->scratch); (void)hipFree(h->fixq); (void)hipFree(h->redo_tiles);
+    (void)hipFree(h->stats2[0]); (void)hipFree(h->stats2[1]); (void)hipFree(h->scratch); (void)hipFree(h->fixq); (void)hipFree(h->redo_tiles); (void)hipFree(h->fixw); (void)hipFree(h->fixw_counts);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -997,7 +1056,14 @@ int dw_kernel_info(dw_handle* h, char* buf, size_t buflen) {
     NEED(h && buf && buflen, DW_EINVAL, "null argument");
     const dw_params& p = h->prm;
     const char* prec = p.precision == DW_PRECISION_EXACT ? "exact" : (p.precision == DW_PRECISION_FAST ? "fast" : "f64");
-    if (h->tcq) {
+    if (h->use_stream && p.precision != DW_PRECISION_F64) {
+        const StripGeom& g = h->sgeom;
+        snprintf(buf, buflen,
+                 "step_stream<%s,halo=%s> wave-strip=%dx256 cells, 3-row register window + 3 rows in flight, "
+                 "%d strips, grid=%d x 256 threads (4 strips each), XCD-chunked",
+                 prec, p.width == 256 ? "rotate" : (p.width % 256 == 0 ? "dpp-old" : "general"), g.SR, g.nstrips,
+                 g.chunk * 8);
+    } else if (h->tcq) {
         const int TR = (256 / h->tcq) * h->rpt;
         snprintf(buf, buflen,
                  "step_tiled<TCQ=%d,RPT=%d,%s> tile=%dx%d cells, %zu B LDS/workgroup, %d tiles, grid=%d x 256 threads, "

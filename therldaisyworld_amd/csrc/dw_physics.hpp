@@ -83,6 +83,56 @@ __host__ __device__ inline CellF64 cell_f64(const PhysF64& P, const double* l, c
     return o;
 }
 
+// k / 1000.0 for an integer k in [0, 65535] WITHOUT a division: one Newton correction of k * 0.001
+// is the correctly rounded quotient for every such k (checked exhaustively; tests/test_gpu_parity).
+__host__ __device__ inline double dw_permille_to_natural(double k) {
+    const double r = 0.001;
+    const double q = k * r;
+    return fma(fma(-q, 1000.0, k), r, q);
+}
+
+// Lean float64 evaluation for the exact mode's fix-up kernels: only the two new covers, and the
+// chain T_eff -> T -> T_x of the reference collapsed to T_x^4 = q2 (A_l - a_x) + q (A - A_l) +
+// S L (1 - A) / sigma (the intermediate fourth roots cancel; the difference to the staged form is a
+// few 1e-16 relative, the size of the reference's own FFT noise).  w[9]: (light | dark << 16)
+// per-mille pairs of the 3x3 neighbourhood, row-major.
+struct NewCoverF64 { double nl, nd; };
+__device__ inline NewCoverF64 cell_f64_lean(const PhysF64& P, const unsigned int* w) {
+    double l[9], d[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        l[i] = dw_permille_to_natural((double)(w[i] & 0xffffu));
+        d[i] = dw_permille_to_natural((double)(w[i] >> 16));
+    }
+    double sb = 0.0, sl = 0.0, sd = 0.0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        if (i == 4) continue;
+        sb += 0.125 * (P.p - l[i] - d[i]);
+        sl += 0.125 * l[i];
+        sd += 0.125 * d[i];
+    }
+    const double bare = P.p - l[4] - d[4];
+    double Al = 0.0, A = 0.0;
+    Al += P.ab * bare; A += P.ab * sb;
+    Al += P.al * l[4]; A += P.al * sl;
+    Al += P.ad * d[4]; A += P.ad * sd;
+    const double T4 = P.q * (A - Al) + (P.S * P.L * (1.0 - A)) / P.sigma;
+    const double Tl = dw_root4(P.q2 * (Al - P.al) + T4);
+    const double Td = dw_root4(P.q2 * (Al - P.ad) + T4);
+    const double bl = 1.0 - P.g * (P.To - Tl) * (P.To - Tl);
+    const double bd = 1.0 - P.g * (P.To - Td) * (P.To - Td);
+    const double kl = P.w0 * l[4] + P.w1 * (l[1] + l[3] + l[5] + l[7]) + P.w2 * (l[0] + l[2] + l[6] + l[8]);
+    const double kd = P.w0 * d[4] + P.w1 * (d[1] + d[3] + d[5] + d[7]) + P.w2 * (d[0] + d[2] + d[6] + d[8]);
+    const double kb = P.p - kl - kd;
+    const double nl = l[4] + P.dt * (kl * (kb * bl - P.gamma));
+    const double nd = d[4] + P.dt * (kd * (kb * bd - P.gamma));
+    NewCoverF64 o;
+    o.nl = nl < 0.0 ? 0.0 : (nl > 1.0 ? 1.0 : nl);
+    o.nd = nd < 0.0 ? 0.0 : (nd > 1.0 ? 1.0 : nd);
+    return o;
+}
+
 // ---------------------------------------------------------------------------------------------
 // float32 fused form
 // ---------------------------------------------------------------------------------------------
