@@ -82,9 +82,6 @@ struct dw_handle {
     // streaming kernel (W >= 256)
     bool use_stream = false;
     StripGeom sgeom{};
-    uint4* fixw = nullptr;            // exact mode: per-workgroup near-tie regions [nwg][cap][3]
-    unsigned int* fixw_counts = nullptr;
-    unsigned int wcap = 0;
     int* done_at = nullptr;           // [B]
     int* agents_done_at = nullptr;    // [B][N]
     int* n_alive = nullptr;
@@ -114,13 +111,7 @@ static int ensure_scratch(dw_handle* h, size_t bytes) {
 static int ensure_fixq(dw_handle* h) {
     const dw_params& p = h->prm;
     if (p.precision != DW_PRECISION_EXACT) return DW_OK;
-    if (h->use_stream) {
-        if (h->fixw) return DW_OK;
-        h->wcap = (unsigned int)((4 * h->sgeom.SR * 256) / 64 < 256 ? 256 : (4 * h->sgeom.SR * 256) / 64);
-        HIPCHK(hipMalloc(&h->fixw, sizeof(uint4) * 3 * (size_t)h->wcap * h->sgeom.nwg));
-        HIPCHK(hipMalloc(&h->fixw_counts, sizeof(unsigned int) * h->sgeom.nwg));
-        return DW_OK;
-    }
+    if (h->use_stream) return DW_OK;        // the streaming kernel keeps its near-tie queues in LDS
     if (h->fixq || p.width % 4 != 0 || p.width < 64) return DW_OK;
     size_t per_q = (h->cells / 64 + kNumQueues - 1) / kNumQueues;
     if (per_q < 2048) per_q = 2048;
@@ -341,13 +332,11 @@ static int launch_forward(dw_handle* h, double L) {
     } else if (h->use_stream) {
         const bool ex = prec == DW_PRECISION_EXACT;
         const StripGeom& g = h->sgeom;
-        FixW fw;
-        fw.entries = h->fixw; fw.counts = h->fixw_counts; fw.cap = h->wcap;
         const dim3 grid((unsigned)g.chunk * 8u);
         const int halo = p.width == 256 ? 0 : (p.width % 256 == 0 ? 1 : 2);
 #define DW_STREAM(K, HL)                                                                                \
     hipLaunchKernelGGL((K<HL>), grid, dim3(256), 0, h->stream, h->L32[in], h->D32[in], h->L32[out],     \
-                       h->D32[out], g, P, stats, fixups, zero_me, zero_n, fw)
+                       h->D32[out], g, P, P64, stats, fixups, zero_me, zero_n)
         if (ex) {
             if (halo == 0) DW_STREAM(step_stream_exact, 0);
             else if (halo == 1) DW_STREAM(step_stream_exact, 1);
@@ -359,11 +348,6 @@ static int launch_forward(dw_handle* h, double L) {
         }
 #undef DW_STREAM
         HIPCHK(hipGetLastError());
-        if (ex) {
-            hipLaunchKernelGGL(fixup_stream, dim3((fw.cap + 255) / 256, (unsigned)g.nwg), dim3(256), 0, h->stream,
-                               h->L32[in], h->D32[in], h->L32[out], h->D32[out], g, P64, stats, fw);
-            HIPCHK(hipGetLastError());
-        }
     } else {
         const bool ex = prec == DW_PRECISION_EXACT;
         int rc;
@@ -492,6 +476,7 @@ int dw_create(const dw_params* p, dw_handle** out) {
     TRY(hipMalloc(&h->agents_done_at, sizeof(int) * bn));
     TRY(hipMalloc(&h->done_at, sizeof(int) * p->batch));
     TRY(hipMalloc(&h->n_alive, sizeof(int)));
+    // [(B+1) StatsDev][(kNumQueues+1)*16 uint queue counters]
     h->stats_bytes = sizeof(StatsDev) * (p->batch + 1) + sizeof(unsigned int) * (kNumQueues + 1) * 16;
     for (int i = 0; i < 2; ++i) {
         TRY(hipMalloc(&h->stats2[i], h->stats_bytes));
@@ -520,7 +505,7 @@ int dw_destroy(dw_handle* h) {
     (void)hipFree(h->idx); (void)hipFree(h->st); (void)hipFree(h->action); (void)hipFree(h->action_tmp);
     (void)hipFree(h->reward_d); (void)hipFree(h->done_d);
     (void)hipFree(h->agents_done_at); (void)hipFree(h->done_at); (void)hipFree(h->n_alive);
-    (void)hipFree(h->stats2[0]); (void)hipFree(h->stats2[1]); (void)hipFree(h->scratch); (void)hipFree(h->fixq); (void)hipFree(h->redo_tiles); (void)hipFree(h->fixw); (void)hipFree(h->fixw_counts);
+    (void)hipFree(h->stats2[0]); (void)hipFree(h->stats2[1]); (void)hipFree(h->scratch); (void)hipFree(h->fixq); (void)hipFree(h->redo_tiles);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -1059,9 +1044,11 @@ int dw_kernel_info(dw_handle* h, char* buf, size_t buflen) {
     if (h->use_stream && p.precision != DW_PRECISION_F64) {
         const StripGeom& g = h->sgeom;
         snprintf(buf, buflen,
-                 "step_stream<%s,halo=%s> wave-strip=%dx256 cells, 3-row register window + 3 rows in flight, "
-                 "%d strips, grid=%d x 256 threads (4 strips each), XCD-chunked",
-                 prec, p.width == 256 ? "rotate" : (p.width % 256 == 0 ? "dpp-old" : "general"), g.SR, g.nstrips,
+                 "step_stream_%s<halo=%s> wave-strip=%dx256 cells, register window + DPP neighbours, %d-row blocks in "
+                 "flight%s, %d strips, grid=%d x 256 threads (4 strips each), XCD-chunked",
+                 prec, p.width == 256 ? "rotate" : (p.width % 256 == 0 ? "dpp-old" : "general"), g.SR,
+                 p.precision == DW_PRECISION_EXACT ? DW_STREAM_RB_EXACT : DW_STREAM_RB_FAST,
+                 p.precision == DW_PRECISION_EXACT ? ", in-wave float64 fix-up from an LDS queue" : "", g.nstrips,
                  g.chunk * 8);
     } else if (h->tcq) {
         const int TR = (256 / h->tcq) * h->rpt;

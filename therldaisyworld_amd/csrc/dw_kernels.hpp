@@ -507,9 +507,11 @@ __global__ __launch_bounds__(256) void redo_tiles_f64(const float* __restrict__ 
 // lanes 0-31 fetch the left halo column and lanes 32-63 the right one (the DPP "old" operand then
 // drops them into lanes 0 and 63).  No barrier in the loop: waves run independently.
 //
-// Exact mode: a near-tie cell's 3x3 neighbourhood is already in the window registers, so its
-// fix-up entry (same 48-byte layout as FixQ) is written straight to the workgroup's private region
-// of the global queue (slot from an LDS atomic, no global atomics); `fixup_stream` consumes it.
+// Exact mode needs no second kernel: a near-tie cell's 3x3 neighbourhood is already in the window
+// registers, so its 48-byte payload (layout of FixQ) goes into the wave's own LDS queue (slots from
+// ballot + mbcnt, no atomics), and when the strip is finished the same wave re-evaluates its queue
+// in float64, one entry per lane, patches its own stores and corrects its reductions.  A strip
+// whose queue overflows is recomputed whole in float64 at that point.
 //
 // HALO: 0 = W == 256 (rotate), 1 = W a multiple of 256 (every strip full), 2 = general (W % 4 == 0).
 // ---------------------------------------------------------------------------------------------
@@ -532,12 +534,6 @@ struct StripGeom {
     int nstrips;              // B * nrs * ncs
     int nwg;                  // ceil(nstrips / 4) workgroups of 4 waves
     int chunk;                // ceil(nwg / 8): workgroups per XCD
-};
-
-struct FixW {                 // per-workgroup near-tie regions (exact mode)
-    uint4* entries;           // [nwg][cap][3]
-    unsigned int* counts;     // [nwg]; 0xffffffff = region overflowed, recompute the whole workgroup
-    unsigned int cap;
 };
 
 struct Raw {                  // one row as loaded: own 4 columns of both planes + the halo column values
@@ -603,285 +599,214 @@ __device__ __forceinline__ void pack3(const Row4& L, const Row4& D, unsigned int
     w2 = (unsigned)lc | ((unsigned)dc << 16);
 }
 
-// queue cell I of the current row (if flagged) into the workgroup's near-tie region
+constexpr int kWaveQueueCap = 256;          // near-tie entries per wave-strip held in LDS (48 B each)
+
 template <int I>
-__device__ __forceinline__ void push_ties(unsigned int ties, unsigned int& s_n, const FixW& fw, int wg, int b,
-                                          int row, int colq, const Row4& upL, const Row4& miL, const Row4& dnL,
-                                          const Row4& upD, const Row4& miD, const Row4& dnD, const float* ol,
-                                          const float* od) {
-    if (!(ties & (1u << I))) return;
-    const unsigned int slot = atomicAdd(&s_n, 1u);
-    if (slot >= fw.cap) return;                      // region full: the whole workgroup is redone in float64
-    unsigned int u0, u1, u2, m0, m1, m2, d0, d1, d2;
-    pack3<I>(upL, upD, u0, u1, u2);
-    pack3<I>(miL, miD, m0, m1, m2);
-    pack3<I>(dnL, dnD, d0, d1, d2);
-    uint4* dst = fw.entries + ((size_t)wg * fw.cap + slot) * 3;
-    dst[0] = make_uint4((unsigned)b, ((unsigned)row << 16) | (unsigned)(colq + I), u0, u1);
-    dst[1] = make_uint4(u2, m0, m1, m2);
-    dst[2] = make_uint4(d0, d1, d2, (unsigned)ol[I] | ((unsigned)od[I] << 16));
+__device__ __forceinline__ void queue_tie(bool tie, unsigned int& n, uint4* __restrict__ q, int b, int row, int colq,
+                                          const Row4& upL, const Row4& miL, const Row4& dnL, const Row4& upD,
+                                          const Row4& miD, const Row4& dnD, const float* ol, const float* od) {
+    const unsigned long long mask = __ballot(tie);
+    if (mask == 0ull) return;                                   // wave-uniform
+    if (tie) {
+        const unsigned int slot = n + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                                __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+        if (slot < (unsigned)kWaveQueueCap) {
+            unsigned int u0, u1, u2, m0, m1, m2, d0, d1, d2;
+            pack3<I>(upL, upD, u0, u1, u2);
+            pack3<I>(miL, miD, m0, m1, m2);
+            pack3<I>(dnL, dnD, d0, d1, d2);
+            uint4* dst = q + slot * 3;
+            dst[0] = make_uint4((unsigned)b, ((unsigned)row << 16) | (unsigned)(colq + I), u0, u1);
+            dst[1] = make_uint4(u2, m0, m1, m2);
+            dst[2] = make_uint4(d0, d1, d2, (unsigned)ol[I] | ((unsigned)od[I] << 16));
+        }
+    }
+    n += (unsigned)__popcll(mask);
 }
 
 template <bool EXACT, int HALO, int RB>
 __device__ __forceinline__ void stream_body(const float* __restrict__ inL, const float* __restrict__ inD,
                                             float* __restrict__ outL, float* __restrict__ outD, const StripGeom& G,
-                                            const PhysF32& P, StatsDev* __restrict__ stats,
+                                            const PhysF32& P, const PhysF64& P64, StatsDev* __restrict__ stats,
                                             unsigned long long* __restrict__ fixups,
-                                            unsigned long long* __restrict__ zero_me, int zero_n, const FixW& fw) {
-    __shared__ unsigned int s_n;
-    __shared__ float s_stat[4][3];
-    __shared__ int s_world[4];
-
+                                            unsigned long long* __restrict__ zero_me, int zero_n) {
+    __shared__ uint4 s_queue[EXACT ? 4 * kWaveQueueCap * 3 : 1];
     const int bid = blockIdx.x;
     const int wg = (bid & 7) * G.chunk + (bid >> 3);            // XCD-aware: contiguous run per XCD
     if (wg >= G.nwg) return;
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
-    if (tid == 0) s_n = 0;
     if (wg == 0)
         for (int i = tid; i < zero_n; i += 256) zero_me[i] = 0ull;
-    if (EXACT) __syncthreads();
-
+    uint4* q = s_queue + (EXACT ? wv * kWaveQueueCap * 3 : 0);
     const int s = wg * 4 + wv;                                  // this wave's strip
+    if (s >= G.nstrips) return;                                 // waves are independent: no barrier anywhere
+    const int spw = G.nrs * G.ncs;
+    const int b = s / spw;
+    const int sw = s - b * spw;
+    const int rs = sw / G.ncs, cs = sw - rs * G.ncs;
+    const int r0 = rs * G.SR, c0 = cs * 256;
+    const int nr = min(G.SR, G.H - r0);
+    const int ncq = min(64, (G.W - c0) >> 2);               // active lanes (4 columns each)
+    const int last_lane = ncq - 1;
+    const bool active = lane < ncq;
+    const size_t woff = (size_t)b * G.H * G.W;
+    const int colq = c0 + 4 * min(lane, last_lane);         // inactive lanes shadow the last active one
+    int hcol = lane < 32 ? c0 - 1 : c0 + 4 * ncq;           // halo column of this lane's half-wave
+    hcol = hcol < 0 ? hcol + G.W : (hcol >= G.W ? hcol - G.W : hcol);
+    const float* pL = inL + woff;
+    const float* pD = inD + woff;
+    const int last_row = r0 + nr;                           // one past the strip: the bottom halo row
     float acc_max = 0.f, acc_l = 0.f, acc_d = 0.f;
-    int b = -1;
-    if (s < G.nstrips) {
-        const int spw = G.nrs * G.ncs;
-        b = s / spw;
-        const int sw = s - b * spw;
-        const int rs = sw / G.ncs, cs = sw - rs * G.ncs;
-        const int r0 = rs * G.SR, c0 = cs * 256;
-        const int nr = min(G.SR, G.H - r0);
-        const int ncq = min(64, (G.W - c0) >> 2);               // active lanes (4 columns each)
-        const int last_lane = ncq - 1;
-        const bool active = lane < ncq;
-        const size_t woff = (size_t)b * G.H * G.W;
-        const int colq = c0 + 4 * min(lane, last_lane);         // inactive lanes shadow the last active one
-        int hcol = lane < 32 ? c0 - 1 : c0 + 4 * ncq;           // halo column of this lane's half-wave
-        hcol = hcol < 0 ? hcol + G.W : (hcol >= G.W ? hcol - G.W : hcol);
-        const float* pL = inL + woff;
-        const float* pD = inD + woff;
-        const int last_row = r0 + nr;                           // one past the strip: the bottom halo row
+    unsigned int nq = 0;                                    // entries queued by this wave (uniform)
 
-        auto load_raw = [&](int rr) -> Raw {                    // rr in [r0-1, r0+nr], clamped + wrapped
-            rr = min(rr, last_row);
-            rr = rr < 0 ? rr + G.H : (rr >= G.H ? rr - G.H : rr);
-            const float* rl = pL + (size_t)rr * G.W;
-            const float* rd = pD + (size_t)rr * G.W;
-            Raw w;
-            w.l = *reinterpret_cast<const float4*>(rl + colq);
-            w.d = *reinterpret_cast<const float4*>(rd + colq);
-            if (HALO != 0) { w.hl = rl[hcol]; w.hd = rd[hcol]; } else { w.hl = 0.f; w.hd = 0.f; }
-            return w;
-        };
-        auto to_rows = [&](const Raw& w, Row4& L, Row4& D) {
-            float a, c;
-            lr_neighbours<HALO>(w.l, w.hl, lane, last_lane, a, c);
-            L = make_row(w.l, a, c);
-            lr_neighbours<HALO>(w.d, w.hd, lane, last_lane, a, c);
-            D = make_row(w.d, a, c);
-        };
+    auto load_raw = [&](int rr) -> Raw {                    // rr in [r0-1, r0+nr], clamped + wrapped
+        rr = min(rr, last_row);
+        rr = rr < 0 ? rr + G.H : (rr >= G.H ? rr - G.H : rr);
+        const float* rl = pL + (size_t)rr * G.W;
+        const float* rd = pD + (size_t)rr * G.W;
+        Raw w;
+        w.l = *reinterpret_cast<const float4*>(rl + colq);
+        w.d = *reinterpret_cast<const float4*>(rd + colq);
+        if (HALO != 0) { w.hl = rl[hcol]; w.hd = rd[hcol]; } else { w.hl = 0.f; w.hd = 0.f; }
+        return w;
+    };
+    auto to_rows = [&](const Raw& w, Row4& L, Row4& D) {
+        float a, c;
+        lr_neighbours<HALO>(w.l, w.hl, lane, last_lane, a, c);
+        L = make_row(w.l, a, c);
+        lr_neighbours<HALO>(w.d, w.hd, lane, last_lane, a, c);
+        D = make_row(w.d, a, c);
+    };
 
-        // All waves advance at the same pace, so if every wave started at the top of its strip the
-        // chip would at any instant touch addresses that are equal modulo the strip size (64 KB for
-        // W = 256) and camp on a few HBM channels.  Each wave therefore starts `phase` rows into its
-        // strip and wraps around: segment 0 = rows [phase, nr), segment 1 = rows [0, phase).
-        const int phase = (int)(((unsigned)s * 27u) % (unsigned)nr);
-        for (int seg = 0; seg < 2; ++seg) {
-            const int kbeg = seg == 0 ? phase : 0, kend = seg == 0 ? nr : phase;
-            if (kbeg >= kend) continue;
-            // Register window of RB+2 converted rows: W[0] = row k-1, W[1..RB] = the RB rows this
-            // block updates, W[RB+1] = row k+RB.  Each loop iteration first issues the loads of the
-            // RB rows the NEXT block needs, then does the arithmetic of this block (which hides their
-            // latency), and only then converts them into the window: the loads are produced and
-            // consumed inside one iteration, so nothing loaded is carried around the loop.
-            Row4 WL[RB + 2], WD[RB + 2];
-            {
-                Raw p[RB + 2];
+    Row4 WL[RB + 2], WD[RB + 2];
+    {
+        Raw p[RB + 2];
 #pragma unroll
-                for (int j = 0; j < RB + 2; ++j) p[j] = load_raw(r0 + kbeg - 1 + j);
+        for (int j = 0; j < RB + 2; ++j) p[j] = load_raw(r0 - 1 + j);
 #pragma unroll
-                for (int j = 0; j < RB + 2; ++j) to_rows(p[j], WL[j], WD[j]);
+        for (int j = 0; j < RB + 2; ++j) to_rows(p[j], WL[j], WD[j]);
+    }
+    auto row_math = [&](const Row4& upL, const Row4& miL, const Row4& dnL, const Row4& upD, const Row4& miD,
+                        const Row4& dnD, int k) {
+        float ol[4], od[4];
+        bool tie[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float El = miL.h2[i] + (upL.x[i] + dnL.x[i]);
+            const float Cl = upL.h2[i] + dnL.h2[i];
+            const float Ed = miD.h2[i] + (upD.x[i] + dnD.x[i]);
+            const float Cd = upD.h2[i] + dnD.h2[i];
+            const GrowthF32 g = growth_f32(P, miL.x[i], miD.x[i], El, Cl, Ed, Cd);
+            if (EXACT) {
+                bool tl, td;
+                ol[i] = finish_exact(P, miL.x[i], g.gql, g.dKl, g.oml, tl);
+                od[i] = finish_exact(P, miD.x[i], g.gqd, g.dKd, g.omd, td);
+                tie[i] = (tl || td) && (HALO != 2 || active);
+                acc_max = fmaxf(acc_max, tie[i] ? 0.f : fmaxf(ol[i], od[i]));
+            } else {
+                ol[i] = finish_fast(miL.x[i], g.gql);
+                od[i] = finish_fast(miD.x[i], g.gqd);
+                acc_max = fmaxf(acc_max, fmaxf(ol[i], od[i]));
             }
-            auto row_math = [&](const Row4& upL, const Row4& miL, const Row4& dnL, const Row4& upD, const Row4& miD,
-                                const Row4& dnD, int k) {
-                float ol[4], od[4];
-                unsigned int ties = 0;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float El = miL.h2[i] + (upL.x[i] + dnL.x[i]);
-                    const float Cl = upL.h2[i] + dnL.h2[i];
-                    const float Ed = miD.h2[i] + (upD.x[i] + dnD.x[i]);
-                    const float Cd = upD.h2[i] + dnD.h2[i];
-                    const GrowthF32 g = growth_f32(P, miL.x[i], miD.x[i], El, Cl, Ed, Cd);
-                    if (EXACT) {
-                        bool tl, td;
-                        ol[i] = finish_exact(P, miL.x[i], g.gql, g.dKl, g.oml, tl);
-                        od[i] = finish_exact(P, miD.x[i], g.gqd, g.dKd, g.omd, td);
-                        const bool tie = (tl || td) && (HALO != 2 || active);
-                        ties |= (tie ? 1u : 0u) << i;
-                        acc_max = fmaxf(acc_max, tie ? 0.f : fmaxf(ol[i], od[i]));
-                    } else {
-                        ol[i] = finish_fast(miL.x[i], g.gql);
-                        od[i] = finish_fast(miD.x[i], g.gqd);
-                        acc_max = fmaxf(acc_max, fmaxf(ol[i], od[i]));
-                    }
-                    acc_l += ol[i]; acc_d += od[i];
-                }
-                if (HALO != 2 || active) {                      // HALO 0/1: every lane owns real columns
-                    const size_t off = woff + (size_t)(r0 + k) * G.W + colq;
-                    *reinterpret_cast<float4*>(outL + off) = make_float4(ol[0], ol[1], ol[2], ol[3]);
-                    *reinterpret_cast<float4*>(outD + off) = make_float4(od[0], od[1], od[2], od[3]);
-                }
-                if (EXACT && ties) {
-                    push_ties<0>(ties, s_n, fw, wg, b, r0 + k, colq, upL, miL, dnL, upD, miD, dnD, ol, od);
-                    push_ties<1>(ties, s_n, fw, wg, b, r0 + k, colq, upL, miL, dnL, upD, miD, dnD, ol, od);
-                    push_ties<2>(ties, s_n, fw, wg, b, r0 + k, colq, upL, miL, dnL, upD, miD, dnD, ol, od);
-                    push_ties<3>(ties, s_n, fw, wg, b, r0 + k, colq, upL, miL, dnL, upD, miD, dnD, ol, od);
-                }
-            };
-            int k = kbeg;
-            for (; k + RB <= kend; k += RB) {
-                Raw nx[RB];
-#pragma unroll
-                for (int j = 0; j < RB; ++j) nx[j] = load_raw(r0 + k + RB + 1 + j);
-                __builtin_amdgcn_sched_barrier(0);              // loads first, then the arithmetic
-#pragma unroll
-                for (int j = 0; j < RB; ++j) row_math(WL[j], WL[j + 1], WL[j + 2], WD[j], WD[j + 1], WD[j + 2], k + j);
-                __builtin_amdgcn_sched_barrier(0);
-                WL[0] = WL[RB]; WD[0] = WD[RB];
-                WL[1] = WL[RB + 1]; WD[1] = WD[RB + 1];
-#pragma unroll
-                for (int j = 0; j < RB; ++j) to_rows(nx[j], WL[2 + j], WD[2 + j]);
-            }
-#pragma unroll
-            for (int j = 0; j < RB - 1; ++j)                    // tail: < RB rows left, already in the window
-                if (k + j < kend) row_math(WL[j], WL[j + 1], WL[j + 2], WD[j], WD[j + 1], WD[j + 2], k + j);
+            acc_l += ol[i]; acc_d += od[i];
         }
-        if (!active) { acc_max = 0.f; acc_l = 0.f; acc_d = 0.f; }
+        if (HALO != 2 || active) {                          // HALO 0/1: every lane owns real columns
+            const size_t off = woff + (size_t)(r0 + k) * G.W + colq;
+            *reinterpret_cast<float4*>(outL + off) = make_float4(ol[0], ol[1], ol[2], ol[3]);
+            *reinterpret_cast<float4*>(outD + off) = make_float4(od[0], od[1], od[2], od[3]);
+        }
+        if (EXACT) {
+            queue_tie<0>(tie[0], nq, q, b, r0 + k, colq, upL, miL, dnL, upD, miD, dnD, ol, od);
+            queue_tie<1>(tie[1], nq, q, b, r0 + k, colq, upL, miL, dnL, upD, miD, dnD, ol, od);
+            queue_tie<2>(tie[2], nq, q, b, r0 + k, colq, upL, miL, dnL, upD, miD, dnD, ol, od);
+            queue_tie<3>(tie[3], nq, q, b, r0 + k, colq, upL, miL, dnL, upD, miD, dnD, ol, od);
+        }
+    };
+    int k = 0;
+    for (; k + RB <= nr; k += RB) {
+        Raw nx[RB];
+#pragma unroll
+        for (int j = 0; j < RB; ++j) nx[j] = load_raw(r0 + k + RB + 1 + j);
+        __builtin_amdgcn_sched_barrier(0);                  // loads first, then the arithmetic
+#pragma unroll
+        for (int j = 0; j < RB; ++j) row_math(WL[j], WL[j + 1], WL[j + 2], WD[j], WD[j + 1], WD[j + 2], k + j);
+        __builtin_amdgcn_sched_barrier(0);
+        WL[0] = WL[RB]; WD[0] = WD[RB];
+        WL[1] = WL[RB + 1]; WD[1] = WD[RB + 1];
+#pragma unroll
+        for (int j = 0; j < RB; ++j) to_rows(nx[j], WL[2 + j], WD[2 + j]);
+    }
+#pragma unroll
+    for (int j = 0; j < RB - 1; ++j)                        // tail: < RB rows left, already in the window
+        if (k + j < nr) row_math(WL[j], WL[j + 1], WL[j + 2], WD[j], WD[j + 1], WD[j + 2], k + j);
+    if (HALO == 2 && !active) { acc_max = 0.f; acc_l = 0.f; acc_d = 0.f; }
+
+    // ---- exact mode: float64 re-evaluation of this wave's queued near-tie cells ----
+    if (EXACT) {
+        if (nq <= (unsigned)kWaveQueueCap) {
+            for (unsigned int e = lane; e < nq; e += 64) {
+                const uint4 e0 = q[e * 3], e1 = q[e * 3 + 1], e2 = q[e * 3 + 2];
+                const unsigned int w[9] = {e0.z, e0.w, e1.x, e1.y, e1.z, e1.w, e2.x, e2.y, e2.z};
+                const NewCoverF64 o = cell_f64_lean(P64, w);
+                const float kl = (float)dw_round3_k(o.nl), kd = (float)dw_round3_k(o.nd);
+                const size_t off = woff + (size_t)(e0.y >> 16) * G.W + (e0.y & 0xffffu);
+                outL[off] = kl;                             // after this wave's own float4 store of the row
+                outD[off] = kd;
+                acc_l += kl - (float)(e2.w & 0xffffu);
+                acc_d += kd - (float)(e2.w >> 16);
+                acc_max = fmaxf(acc_max, fmaxf(kl, kd));
+            }
+        } else {                                            // queue overflow: the whole strip in float64
+            acc_max = 0.f; acc_l = 0.f; acc_d = 0.f;
+            const int nc = min(256, G.W - c0);
+            for (int i = lane; i < nr * nc; i += 64) {
+                const int r = r0 + i / nc, c = c0 + i % nc;
+                double l9[9], d9[9];
+                gather9(pL, G.H, G.W, r, c, l9);
+                gather9(pD, G.H, G.W, r, c, d9);
+                const CellF64 o = cell_f64(P64, l9, d9);
+                const float kl = (float)dw_round3_k(o.nl), kd = (float)dw_round3_k(o.nd);
+                outL[woff + (size_t)r * G.W + c] = kl;
+                outD[woff + (size_t)r * G.W + c] = kd;
+                acc_l += kl; acc_d += kd;
+                acc_max = fmaxf(acc_max, fmaxf(kl, kd));
+            }
+        }
     }
 
-    // per-world reductions of this wave's strip: wavefront shuffles
+    // per-world reductions of this strip: wavefront shuffles, three atomics per strip
     const float m = wave_max(acc_max);
     const float sl = wave_sum(acc_l), sd = wave_sum(acc_d);
-    bool redo = false;
-    if (EXACT) {
-        if (lane == 0) { s_stat[wv][0] = m; s_stat[wv][1] = sl; s_stat[wv][2] = sd; s_world[wv] = b; }
-        __syncthreads();
-        const unsigned int n = s_n;
-        redo = n > fw.cap;
-        if (tid == 0) {
-            fw.counts[wg] = redo ? 0xffffffffu : n;
-            if (!redo && n) atomicAdd(fixups, (unsigned long long)n);
-        }
-    }
-    if (lane == 0 && b >= 0 && !redo) {
+    if (lane == 0) {
         atomicMax(&stats[b].max_k, (unsigned int)m);
         atomicAdd(&stats[b].sum_l, (unsigned long long)sl);
         atomicAdd(&stats[b].sum_d, (unsigned long long)sd);
+        if (EXACT && nq) atomicAdd(fixups, (unsigned long long)nq);
     }
+
+
 }
 
 // Two entry points so that each arithmetic mode gets its own register budget: the float32-only
 // kernel fits 4 waves per SIMD with 2-row blocks; the exact kernel carries the tie test and the
-// fix-up payload path and is planned for 3 waves per SIMD (<= 168 VGPRs).
+// fix-up path and is planned for 3 waves per SIMD (<= 168 VGPRs; its 48 KB of LDS queues per
+// workgroup allow 3 workgroups per CU as well).
 template <int HALO>
 __global__ __launch_bounds__(256) void step_stream_fast(const float* __restrict__ inL, const float* __restrict__ inD,
                                                         float* __restrict__ outL, float* __restrict__ outD,
-                                                        StripGeom G, PhysF32 P, StatsDev* __restrict__ stats,
+                                                        StripGeom G, PhysF32 P, PhysF64 P64,
+                                                        StatsDev* __restrict__ stats,
                                                         unsigned long long* __restrict__ fixups,
-                                                        unsigned long long* __restrict__ zero_me, int zero_n, FixW fw) {
-    stream_body<false, HALO, DW_STREAM_RB_FAST>(inL, inD, outL, outD, G, P, stats, fixups, zero_me, zero_n, fw);
+                                                        unsigned long long* __restrict__ zero_me, int zero_n) {
+    stream_body<false, HALO, DW_STREAM_RB_FAST>(inL, inD, outL, outD, G, P, P64, stats, fixups, zero_me, zero_n);
 }
 
 template <int HALO>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DW_STREAM_WAVES_EXACT, DW_STREAM_WAVES_EXACT)))
 void step_stream_exact(const float* __restrict__ inL, const float* __restrict__ inD, float* __restrict__ outL,
-                       float* __restrict__ outD, StripGeom G, PhysF32 P, StatsDev* __restrict__ stats,
-                       unsigned long long* __restrict__ fixups, unsigned long long* __restrict__ zero_me, int zero_n,
-                       FixW fw) {
-    stream_body<true, HALO, DW_STREAM_RB_EXACT>(inL, inD, outL, outD, G, P, stats, fixups, zero_me, zero_n, fw);
-}
-
-// fixup_stream — second kernel of an exact-mode step after step_stream.  grid = (ceil(cap/256), nwg).
-// Normal role: dense float64 re-evaluation of workgroup `wg`'s queued near-tie cells (see fixup_cells).
-// If the workgroup's region overflowed (count 0xffffffff) the blocks of this row instead recompute
-// all cells of the workgroup's four strips in float64 from the pre-step planes.
-__global__ __launch_bounds__(256) void fixup_stream(const float* __restrict__ inL, const float* __restrict__ inD,
-                                                    float* __restrict__ outL, float* __restrict__ outD, StripGeom G,
-                                                    PhysF64 P64, StatsDev* __restrict__ stats, FixW fw) {
-    const unsigned int wg = blockIdx.y;
-    const unsigned int n = fw.counts[wg];
-    if (n != 0xffffffffu) {
-        const unsigned int e = blockIdx.x * 256 + threadIdx.x;
-        if (blockIdx.x * 256 >= n) return;
-        const bool active = e < n;
-        int world = -1;
-        float kl = 0.f, kd = 0.f, dl = 0.f, dd = 0.f;
-        if (active) {
-            const uint4* src = fw.entries + ((size_t)wg * fw.cap + e) * 3;
-            const uint4 e0 = src[0], e1 = src[1], e2 = src[2];
-            world = (int)e0.x;
-            const int r = (int)(e0.y >> 16), c = (int)(e0.y & 0xffffu);
-            const unsigned int w[9] = {e0.z, e0.w, e1.x, e1.y, e1.z, e1.w, e2.x, e2.y, e2.z};
-            const NewCoverF64 o = cell_f64_lean(P64, w);
-            kl = (float)dw_round3_k(o.nl);
-            kd = (float)dw_round3_k(o.nd);
-            dl = kl - (float)(e2.w & 0xffffu);
-            dd = kd - (float)(e2.w >> 16);
-            const size_t off = (size_t)world * G.H * G.W + (size_t)r * G.W + c;
-            outL[off] = kl;
-            outD[off] = kd;
-        }
-        unsigned long long todo = __ballot(active);
-        while (todo) {
-            const int leader = __ffsll((long long)todo) - 1;
-            const int w = __shfl(world, leader, 64);
-            const bool mine = active && world == w;
-            const float m = wave_max(mine ? fmaxf(kl, kd) : 0.f);
-            const float sl = wave_sum(mine ? dl : 0.f), sd = wave_sum(mine ? dd : 0.f);
-            if ((int)(threadIdx.x & 63) == leader) {
-                atomicMax(&stats[w].max_k, (unsigned int)m);
-                atomicAdd(&stats[w].sum_l, (unsigned long long)(long long)sl);
-                atomicAdd(&stats[w].sum_d, (unsigned long long)(long long)sd);
-            }
-            todo &= ~__ballot(mine);
-        }
-        return;
-    }
-    // overflow role: the four strips of workgroup `wg`, all cells, float64
-    __shared__ unsigned int s_max, s_suml, s_sumd;
-    for (int wv = 0; wv < 4; ++wv) {
-        const int s = (int)wg * 4 + wv;
-        if (s >= G.nstrips) break;
-        const int spw = G.nrs * G.ncs;
-        const int b = s / spw, sw = s - b * spw;
-        const int rs = sw / G.ncs, cs = sw - rs * G.ncs;
-        const int r0 = rs * G.SR, c0 = cs * 256;
-        const int nr = min(G.SR, G.H - r0), nc = min(256, G.W - c0);
-        const size_t woff = (size_t)b * G.H * G.W;
-        if (threadIdx.x == 0) { s_max = 0; s_suml = 0; s_sumd = 0; }
-        __syncthreads();
-        for (int i = blockIdx.x * 256 + threadIdx.x; i < nr * nc; i += gridDim.x * 256) {
-            const int r = r0 + i / nc, c = c0 + i % nc;
-            double l9[9], d9[9];
-            gather9(inL + woff, G.H, G.W, r, c, l9);
-            gather9(inD + woff, G.H, G.W, r, c, d9);
-            const CellF64 o = cell_f64(P64, l9, d9);
-            const float kl = (float)dw_round3_k(o.nl), kd = (float)dw_round3_k(o.nd);
-            outL[woff + (size_t)r * G.W + c] = kl;
-            outD[woff + (size_t)r * G.W + c] = kd;
-            atomicMax(&s_max, (unsigned int)fmaxf(kl, kd));
-            atomicAdd(&s_suml, (unsigned int)kl);
-            atomicAdd(&s_sumd, (unsigned int)kd);
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            atomicMax(&stats[b].max_k, s_max);
-            atomicAdd(&stats[b].sum_l, (unsigned long long)s_suml);
-            atomicAdd(&stats[b].sum_d, (unsigned long long)s_sumd);
-        }
-        __syncthreads();
-    }
+                       float* __restrict__ outD, StripGeom G, PhysF32 P, PhysF64 P64, StatsDev* __restrict__ stats,
+                       unsigned long long* __restrict__ fixups, unsigned long long* __restrict__ zero_me, int zero_n) {
+    stream_body<true, HALO, DW_STREAM_RB_EXACT>(inL, inD, outL, outD, G, P, P64, stats, fixups, zero_me, zero_n);
 }
 
 // ---------------------------------------------------------------------------------------------
