@@ -89,26 +89,27 @@ SIGNATURES = {
     "dw_last_fixup_count": (C.c_int, [_vp, C.POINTER(_u64)]),
 }
 
-_lib = None
+_libs = {}
 
 
-def load():
-    """Load the shared library and declare every prototype.  Raises if it has not been built."""
-    global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
+def load(path=None):
+    """Load the shared library and declare every prototype.  Raises if it has not been built.
+    `path` selects another build of the same ABI (tuning A/B runs); default = the in-tree library."""
+    path = path or LIB_PATH
+    if path not in _libs:
+        if not os.path.exists(path):
             raise ImportError(
-                f"{LIB_PATH} is missing: build the HIP extension first "
+                f"{path} is missing: build the HIP extension first "
                 "(python -m therldaisyworld_amd.build); there is no CPU fallback")
-        lib = C.CDLL(LIB_PATH)
+        lib = C.CDLL(path)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)     # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args
         if lib.dw_abi_version() != DW_ABI_VERSION:
             raise ImportError("libdaisyworld_hip.so ABI version mismatch; rebuild it")
-        _lib = lib
-    return _lib
+        _libs[path] = lib
+    return _libs[path]
 
 
 def check(rc):

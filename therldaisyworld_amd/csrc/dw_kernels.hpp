@@ -536,6 +536,27 @@ struct StripGeom {
     int chunk;                // ceil(nwg / 8): workgroups per XCD
 };
 
+// streaming accesses of the hot kernel.  The new planes are not read again within the step, so they
+// are stored non-temporally; non-temporal LOADS were measured slower (-DDW_NT_LOAD keeps the switch).
+typedef float dw_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 stream_load4(const float* p) {
+#ifdef DW_NT_LOAD
+    const dw_f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const dw_f32x4*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+#else
+    return *reinterpret_cast<const float4*>(p);
+#endif
+}
+__device__ __forceinline__ void stream_store4(float* p, const float4& v) {
+#ifndef DW_NO_NT_STORE      // non-temporal stores: measured -1.5 % (fast) / -6 % (exact) on C2
+    dw_f32x4 t;
+    t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+    __builtin_nontemporal_store(t, reinterpret_cast<dw_f32x4*>(p));
+#else
+    *reinterpret_cast<float4*>(p) = v;
+#endif
+}
+
 struct Raw {                  // one row as loaded: own 4 columns of both planes + the halo column values
     float4 l, d;
     float hl, hd;             // lanes 0-31: column left of the strip; lanes 32-63: column right of it
@@ -665,8 +686,8 @@ __device__ __forceinline__ void stream_body(const float* __restrict__ inL, const
         const float* rl = pL + (size_t)rr * G.W;
         const float* rd = pD + (size_t)rr * G.W;
         Raw w;
-        w.l = *reinterpret_cast<const float4*>(rl + colq);
-        w.d = *reinterpret_cast<const float4*>(rd + colq);
+        w.l = stream_load4(rl + colq);
+        w.d = stream_load4(rd + colq);
         if (HALO != 0) { w.hl = rl[hcol]; w.hd = rd[hcol]; } else { w.hl = 0.f; w.hd = 0.f; }
         return w;
     };
@@ -712,8 +733,8 @@ __device__ __forceinline__ void stream_body(const float* __restrict__ inL, const
         }
         if (HALO != 2 || active) {                          // HALO 0/1: every lane owns real columns
             const size_t off = woff + (size_t)(r0 + k) * G.W + colq;
-            *reinterpret_cast<float4*>(outL + off) = make_float4(ol[0], ol[1], ol[2], ol[3]);
-            *reinterpret_cast<float4*>(outD + off) = make_float4(od[0], od[1], od[2], od[3]);
+            stream_store4(outL + off, make_float4(ol[0], ol[1], ol[2], ol[3]));
+            stream_store4(outD + off, make_float4(od[0], od[1], od[2], od[3]));
         }
         if (EXACT) {
             queue_tie<0>(tie[0], nq, q, b, r0 + k, colq, upL, miL, dnL, upD, miD, dnD, ol, od);

@@ -37,8 +37,8 @@ def default_params(batch, height, width, n_agents) -> DwParams:
 
 
 class Engine:
-    def __init__(self, params: DwParams):
-        self._lib = _ffi.load()
+    def __init__(self, params: DwParams, lib_path=None):
+        self._lib = _ffi.load(lib_path)
         self._h = C.c_void_p()
         self.params = DwParams()
         C.memmove(C.byref(self.params), C.byref(params), C.sizeof(DwParams))
