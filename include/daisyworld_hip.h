@@ -219,6 +219,26 @@ int dw_lifespan_accumulate(dw_handle* h, uint32_t threshold_k);
 int dw_lifespan_download(dw_handle* h, int32_t* done_at /* [B] */, int32_t* agents_done_at /* [B][N] */,
                          int32_t* n_worlds_alive);
 
+/* Device-resident episode loop for small worlds (H*W <= 4096): K consecutive
+ * environment steps — policy, update_agents (ref :181-244), forward (ref :434-461), reductions — in
+ * ONE launch with the worlds held in LDS, no host round trip per step.  It is the body of the
+ * reference's lifespan harness (notebooks/greedy_longevity_abatement.ipynb cell 2:28-57) and of
+ * sges.get_fitness (daisy/evo/sges.py:144-181) for scripted policies.
+ *   L_schedule[K]   luminosity of each step (the caller runs the ref update_L recurrence :463-473)
+ *   policy_mode     DW_POLICY_ARGMAX / DW_POLICY_ARGMIN (ref Greedy, agents/greedy.py:18-30),
+ *                   DW_POLICY_ZEROS (ref step(None): action 0), DW_POLICY_TABLE (all actions given)
+ *   use_table[K]    per step: 1 = this step's actions come from `table` (Greedy's epsilon branch,
+ *                   drawn by the caller from the legacy NumPy stream); may be NULL (all 0)
+ *   table[K][B][N]  int8 action codes; may be NULL if never used
+ *   world_alive[K][B], agent_ok[K][B][N]   per-step flags out: max cover > threshold_k/1000, and
+ *                   reward >= 0.1 (what the harness adds to done_at / agents_done_at)
+ * Needs a quantised current state in exact mode (take the first step of an episode with dw_step).
+ * Afterwards the handle is exactly as after K calls of dw_step (previous state retained). */
+enum { DW_POLICY_ZEROS = 2, DW_POLICY_TABLE = 3 };
+int dw_run_episode(dw_handle* h, int32_t nsteps, const double* L_schedule, int policy_mode,
+                   const uint8_t* use_table, const int8_t* table, uint32_t threshold_k, uint8_t* world_alive,
+                   uint8_t* agent_ok);
+
 /* ---- plumbing ------------------------------------------------------------------------------- */
 
 /* Use an existing HIP stream (e.g. torch's current stream) instead of the handle's own. */

@@ -416,3 +416,121 @@ def test_lifespan_accumulators(amd):
     assert np.array_equal(d, done_at) and np.array_equal(a, agents_done_at)
     assert alive == int((env.grid[:, 1:3].max(axis=(1, 2, 3)) > 0.005).sum())
     env.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# device-resident episode loop
+# ---------------------------------------------------------------------------------------------
+G5_CASES = [(a, d) for a in ("greedy", "antigreedy", "random", "half_random", "no")
+            for d in ("light_and_dark", "neutral_albedo")]
+
+
+def _g5_agent(amd, status):
+    return {"greedy": amd.Greedy(epsilon=0.0), "antigreedy": amd.Greedy(epsilon=0.0, greedy=False),
+            "random": amd.Greedy(epsilon=1.0), "half_random": amd.Greedy(epsilon=0.5), "no": None}[status]
+
+
+@pytest.mark.parametrize("agent_status,daisy_status", G5_CASES)
+def test_device_episode_loop_lifespans_g5(amd, golden, agent_status, daisy_status):
+    """The whole README sweep protocol with the step loop resident on the device: per-world and
+    per-agent lifespans identical to the reference's (all 5 policies x 2 albedo settings)."""
+    from therldaisyworld_amd.harness import simulate_lifespan
+    g = golden("G5_lifespans")
+    B, seed = int(g["B"]), int(g["seed"])
+    np.random.seed(seed)
+    env = amd.RLDaisyWorld(grid_dimension=8)
+    env.batch_size = B
+    if daisy_status == "neutral_albedo":
+        env.albedo_dark = env.albedo_light = env.albedo_bare
+    env.reset()
+    done_at, agents_done_at = simulate_lifespan(env, _g5_agent(amd, agent_status))
+    key = f"{agent_status}_{daisy_status}"
+    assert np.array_equal(done_at, g[key + "_done_at"])
+    assert np.array_equal(agents_done_at, g[key + "_agents_done_at"])
+    env.close()
+
+
+@pytest.mark.parametrize("precision", ["exact", "fast"])
+def test_device_episode_loop_leaves_env_like_host_loop(amd, precision):
+    """After the harness the environment (grid, agents, L, step_count) and the NumPy RNG stream are
+    exactly where the per-step host loop leaves them (16x16 worlds, half-random policy, odd chunk)."""
+    from therldaisyworld_amd.harness import simulate_lifespan
+
+    def run(device_loop):
+        np.random.seed(5)
+        env = amd.RLDaisyWorld(grid_dimension=16, n_agents=3, precision=precision)
+        env.batch_size = 12
+        env.min_L, env.max_L, env.ramp_period = 1.0, 1.6, 64
+        agent = amd.Greedy(epsilon=0.5)
+        d, a = simulate_lifespan(env, agent, chunk=7, use_device_loop=device_loop)
+        out = (d, a, env.grid.copy(), env.agent_indices.copy(), env.agent_states.copy(), env.L, env.step_count,
+               np.random.rand())
+        env.close()
+        return out
+
+    dev, host = run(True), run(False)
+    for x, y in zip(dev, host):
+        assert np.array_equal(x, y)
+
+
+def test_run_episode_matches_stepwise_engine(amd):
+    """dw_run_episode == K x (policy + dw_step): planes, agents, flags, reductions, previous state."""
+    from therldaisyworld_amd import _ffi
+    B, G, N, K = 9, 32, 5, 11
+    outs = []
+    for mode in ("episode", "stepwise"):
+        eng = _engine(amd, B, G, G, N, "exact")
+        eng.init_random(77)
+        L, dL = 1.0, 0.01
+        eng.step(L, np.zeros((B, N, 1), dtype=int))         # quantise the state
+        L += dL
+        Ls = [L + i * dL for i in range(K)]
+        rng = np.random.RandomState(1)
+        use = (rng.rand(K) < 0.4).astype(np.uint8)
+        table = rng.randint(9, size=(K, B, N)).astype(np.int8)
+        if mode == "episode":
+            alive, ok = eng.run_episode(Ls, _ffi.POLICY_ARGMAX, use, table)
+        else:
+            alive, ok = np.zeros((K, B), bool), np.zeros((K, B, N), bool)
+            for t in range(K):
+                if use[t]:
+                    eng.upload_actions(table[t])
+                else:
+                    eng.policy_greedy(argmin=False)
+                eng.step_device_actions(Ls[t])
+                alive[t] = eng.reduce()["max_k"] > 5
+                ok[t] = ~eng.reward_done()[1][..., 0]
+        outs.append((alive, ok, eng.download_planes(), eng.download_planes(1), eng.download_agents(), eng.reduce(),
+                     eng.download_grid(), eng.get_obs()))
+        eng.close()
+    a, b = outs
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    for i in (2, 3, 4):
+        assert np.array_equal(a[i][0], b[i][0]) and np.array_equal(a[i][1], b[i][1])
+    for f in ("max_k", "sum_light_k", "sum_dark_k"):
+        assert np.array_equal(a[5][f], b[5][f])
+    assert np.array_equal(a[6], b[6]) and np.array_equal(a[7], b[7])
+
+
+def test_c1_trajectory_via_episode_kernel_g2(amd, golden):
+    """C1 (64x64, no agents) with the step loop resident on the device: bit-exact snapshots."""
+    from therldaisyworld_amd import _ffi
+    g = golden("G2_c1_trajectory")
+    eng = _engine(amd, 1, 64, 64, 0, "exact")
+    eng.upload_state(g["light0"], g["dark0"])
+    L, dL = 0.75, 0.75 / 512
+    L = eng.step_n(1, L, dL, 0.75, 1.5)                      # first step from the un-quantised state
+    t = 1
+    for snap in (int(s) for s in g["snap_steps"]):
+        if snap > t:
+            Ls = []
+            for _ in range(snap - t):
+                Ls.append(L)
+                L = min(max(L + dL, 0.75), 1.5)
+            eng.run_episode(Ls, _ffi.POLICY_ZEROS)
+            t = snap
+        gl, gd = eng.download_planes()
+        assert np.array_equal(_k(gl).astype(np.uint16), g[f"light_k_{t}"]), t
+        assert np.array_equal(_k(gd).astype(np.uint16), g[f"dark_k_{t}"]), t
+    assert L == float(g["final_L"])
+    eng.close()

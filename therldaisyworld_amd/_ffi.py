@@ -18,7 +18,7 @@ DW_ABI_VERSION = 1
 DW_OK, DW_EINVAL, DW_ENODEVICE, DW_ENOMEM, DW_EHIP, DW_ESTATE = 0, -1, -2, -3, -4, -5
 PRECISION = {"exact": 0, "fast": 1, "f64": 2}
 STATE_CURRENT, STATE_PREVIOUS = 0, 1
-POLICY_ARGMAX, POLICY_ARGMIN = 0, 1
+POLICY_ARGMAX, POLICY_ARGMIN, POLICY_ZEROS, POLICY_TABLE = 0, 1, 2, 3
 
 
 class DaisyHipError(RuntimeError):
@@ -80,6 +80,7 @@ SIGNATURES = {
     "dw_lifespan_reset": (C.c_int, [_vp]),
     "dw_lifespan_accumulate": (C.c_int, [_vp, _u32]),
     "dw_lifespan_download": (C.c_int, [_vp, _pi, _pi, _pi]),
+    "dw_run_episode": (C.c_int, [_vp, _i32, _pd, C.c_int, _pu8, C.POINTER(C.c_int8), _u32, _pu8, _pu8]),
     "dw_set_stream": (C.c_int, [_vp, _vp]),
     "dw_sync": (C.c_int, [_vp]),
     "dw_timer_start": (C.c_int, [_vp]),

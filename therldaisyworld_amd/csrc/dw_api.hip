@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <vector>
 
 #include "../../include/daisyworld_hip.h"
 #include "dw_kernels.hpp"
@@ -87,6 +88,8 @@ struct dw_handle {
     int* n_alive = nullptr;
     double* scratch = nullptr;        // device staging for float64 downloads / uploads
     size_t scratch_bytes = 0;
+    unsigned char* ep_buf = nullptr;  // device staging of dw_run_episode (schedules, tables, flags)
+    size_t ep_bytes = 0;
     double* reward_d = nullptr;       // [B][N]
     unsigned char* done_d = nullptr;  // [B][N]
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -95,6 +98,11 @@ struct dw_handle {
     Geom geom{};
     size_t tile_lds = 0;
 };
+
+static int run_episode_impl(dw_handle* h, int32_t nsteps, const double* L_schedule, int policy_mode,
+                            const uint8_t* use_table, const int8_t* table, uint32_t threshold_k,
+                            uint8_t* world_alive, uint8_t* agent_ok);
+static bool episode_kernel_applies(const dw_handle* h);
 
 static int ensure_scratch(dw_handle* h, size_t bytes) {
     if (h->scratch_bytes >= bytes) return DW_OK;
@@ -505,7 +513,7 @@ int dw_destroy(dw_handle* h) {
     (void)hipFree(h->idx); (void)hipFree(h->st); (void)hipFree(h->action); (void)hipFree(h->action_tmp);
     (void)hipFree(h->reward_d); (void)hipFree(h->done_d);
     (void)hipFree(h->agents_done_at); (void)hipFree(h->done_at); (void)hipFree(h->n_alive);
-    (void)hipFree(h->stats2[0]); (void)hipFree(h->stats2[1]); (void)hipFree(h->scratch); (void)hipFree(h->fixq); (void)hipFree(h->redo_tiles);
+    (void)hipFree(h->stats2[0]); (void)hipFree(h->stats2[1]); (void)hipFree(h->scratch); (void)hipFree(h->ep_buf); (void)hipFree(h->fixq); (void)hipFree(h->redo_tiles);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -807,7 +815,33 @@ int dw_step_n(dw_handle* h, int32_t nsteps, double* L_io, double dL, double min_
     NEED(nsteps >= 0, DW_EINVAL, "nsteps < 0");
     HIPCHK(hipSetDevice(h->prm.device));
     double L = *L_io;
-    for (int s = 0; s < nsteps; ++s) {
+    int s0 = 0;
+    if (!use_device_actions && nsteps > 1 && h->have_state && h->prm.height * h->prm.width <= 4096) {
+        // small worlds: keep the whole run of steps on the chip (worlds in LDS, one launch per 4096 steps)
+        if (!episode_kernel_applies(h)) {          // exact mode from an un-quantised state: one ordinary step first
+            int rc = launch_forward(h, L);
+            if (rc) return rc;
+            L += dL; L = L > max_L ? max_L : L; L = L < min_L ? min_L : L;
+            s0 = 1;
+        }
+        if (episode_kernel_applies(h)) {
+            std::vector<double> Ls;
+            while (s0 < nsteps) {
+                const int k = nsteps - s0 < 4096 ? nsteps - s0 : 4096;
+                Ls.resize(k);
+                for (int i = 0; i < k; ++i) {
+                    Ls[i] = L;
+                    L += dL; L = L > max_L ? max_L : L; L = L < min_L ? min_L : L;
+                }
+                int rc = run_episode_impl(h, k, Ls.data(), kPolicySkipAgents, nullptr, nullptr, 5, nullptr, nullptr);
+                if (rc) return rc;
+                s0 += k;
+            }
+            *L_io = L;
+            return DW_OK;
+        }
+    }
+    for (int s = s0; s < nsteps; ++s) {
         int rc;
         if (use_device_actions) {
             rc = launch_agents(h, h->action, h->prm.batch, h->prm.n_agents);
@@ -990,6 +1024,92 @@ int dw_lifespan_download(dw_handle* h, int32_t* done_at, int32_t* agents_done_at
                               hipMemcpyDeviceToHost, h->stream));
     if (n_worlds_alive) HIPCHK(hipMemcpyAsync(n_worlds_alive, h->n_alive, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    return DW_OK;
+}
+
+int dw_run_episode(dw_handle* h, int32_t nsteps, const double* L_schedule, int policy_mode,
+                   const uint8_t* use_table, const int8_t* table, uint32_t threshold_k, uint8_t* world_alive,
+                   uint8_t* agent_ok) {
+    NEED(h && L_schedule, DW_EINVAL, "null argument");
+    NEED(policy_mode >= 0 && policy_mode <= 3, DW_EINVAL, "bad policy mode");
+    return run_episode_impl(h, nsteps, L_schedule, policy_mode, use_table, table, threshold_k, world_alive, agent_ok);
+}
+
+static bool episode_kernel_applies(const dw_handle* h) {
+    const dw_params& p = h->prm;
+    return p.height * p.width <= 4096 && p.precision != DW_PRECISION_F64 && p.collision_mode == 0 &&
+           (p.precision != DW_PRECISION_EXACT || h->cur_quantised) && !std::getenv("DW_NO_EPISODE_KERNEL");
+}
+
+static int run_episode_impl(dw_handle* h, int32_t nsteps, const double* L_schedule, int policy_mode,
+                            const uint8_t* use_table, const int8_t* table, uint32_t threshold_k,
+                            uint8_t* world_alive, uint8_t* agent_ok) {
+    const dw_params& p = h->prm;
+    HIPCHK(hipSetDevice(p.device));
+    NEED(nsteps >= 1 && nsteps <= 4096, DW_EINVAL, "nsteps must be in 1..4096");
+    NEED(p.precision != DW_PRECISION_F64, DW_EINVAL, "dw_run_episode supports exact and fast precision");
+    NEED(p.collision_mode == 0, DW_EINVAL, "collision_mode=1 is not implemented on the device");
+    const int C = p.height * p.width, N = p.n_agents, B = p.batch;
+    NEED(C <= 4096, DW_EINVAL, "dw_run_episode is for small worlds (H*W <= 4096); use dw_step_n / dw_step");
+    NEED(h->have_state, DW_ESTATE, "no state uploaded");
+    NEED(N == 0 || h->have_agents, DW_ESTATE, "no agents uploaded");
+    NEED(p.precision != DW_PRECISION_EXACT || h->cur_quantised, DW_ESTATE,
+         "exact mode: the current state is not quantised yet; take the first step with dw_step");
+    NEED(policy_mode != DW_POLICY_TABLE || table, DW_EINVAL, "DW_POLICY_TABLE needs a table");
+    if (use_table && !table)
+        for (int t = 0; t < nsteps; ++t) NEED(!use_table[t], DW_EINVAL, "use_table set but no table given");
+    const int wpb = C <= 256 ? 4 : (C <= 1024 ? 2 : 1);
+    const size_t world_bytes = ((size_t)16 * C + (size_t)N * 8 + (size_t)N * 12 + 16 + 15) / 16 * 16;
+    const size_t lds = world_bytes * wpb;
+    NEED(lds <= 160 * 1024, DW_EINVAL, "too many agents for the LDS-resident episode kernel");
+    // device staging: [P32 K][Ls K][use_table K][table K*B*N][world_alive K*B][agent_ok K*B*N]
+    const size_t K = (size_t)nsteps, bn = (size_t)B * N;
+    auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+    const size_t o_p32 = 0, o_ls = up(o_p32 + sizeof(PhysF32) * K), o_ut = up(o_ls + sizeof(double) * K);
+    const size_t o_tab = up(o_ut + K), o_wa = up(o_tab + K * bn), o_ok = up(o_wa + K * B), total = up(o_ok + K * bn);
+    if (h->ep_bytes < total) {
+        if (h->ep_buf) HIPCHK(hipFree(h->ep_buf));
+        h->ep_buf = nullptr; h->ep_bytes = 0;
+        HIPCHK(hipMalloc(&h->ep_buf, total));
+        h->ep_bytes = total;
+    }
+    std::vector<PhysF32> p32(K);
+    for (size_t t = 0; t < K; ++t) p32[t] = derive_f32(p, L_schedule[t]);
+    std::vector<unsigned char> ut(K, 0);
+    if (use_table) std::memcpy(ut.data(), use_table, K);
+    HIPCHK(hipMemcpyAsync(h->ep_buf + o_p32, p32.data(), sizeof(PhysF32) * K, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->ep_buf + o_ls, L_schedule, sizeof(double) * K, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->ep_buf + o_ut, ut.data(), K, hipMemcpyHostToDevice, h->stream));
+    if (table && bn) HIPCHK(hipMemcpyAsync(h->ep_buf + o_tab, table, K * bn, hipMemcpyHostToDevice, h->stream));
+    StatsDev* stats = h->stats2[h->sp];
+    HIPCHK(hipMemsetAsync(stats, 0, sizeof(StatsDev) * (B + 1), h->stream));
+    EpisodeIO io;
+    const int cur = h->cur, prev = 1 - h->cur;
+    io.L = h->L32[cur]; io.D = h->D32[cur]; io.prevL = h->L32[prev]; io.prevD = h->D32[prev];
+    io.idx = h->idx; io.st = h->st;
+    io.P32 = reinterpret_cast<const PhysF32*>(h->ep_buf + o_p32);
+    io.Ls = reinterpret_cast<const double*>(h->ep_buf + o_ls);
+    io.use_table = h->ep_buf + o_ut;
+    io.table = reinterpret_cast<const signed char*>(h->ep_buf + o_tab);
+    io.world_alive = h->ep_buf + o_wa;
+    io.agent_ok = h->ep_buf + o_ok;
+    io.stats = stats;
+    io.fixups = &stats[B].sum_l;
+    const PhysF64 P64 = make_f64(p, L_schedule[0]);
+    const dim3 grid((unsigned)((B + wpb - 1) / wpb));
+    const bool ex = p.precision == DW_PRECISION_EXACT;
+    auto kern = ex ? episode_small<true> : episode_small<false>;
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, h->stream, io, B, N, p.height, p.width, wpb, nsteps, policy_mode,
+                       p.obs_mask, p.agent_gamma, threshold_k, P64);
+    HIPCHK(hipGetLastError());
+    if (world_alive) HIPCHK(hipMemcpyAsync(world_alive, h->ep_buf + o_wa, K * B, hipMemcpyDeviceToHost, h->stream));
+    if (agent_ok && bn) HIPCHK(hipMemcpyAsync(agent_ok, h->ep_buf + o_ok, K * bn, hipMemcpyDeviceToHost, h->stream));
+    h->f64 = F64_NONE;
+    h->cur_quantised = true;
+    h->stepped = true;
+    h->L_last = L_schedule[K - 1];
+    HIPCHK(hipStreamSynchronize(h->stream));      // host vectors above go out of scope; flags are returned
     return DW_OK;
 }
 

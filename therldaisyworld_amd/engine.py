@@ -206,6 +206,24 @@ class Engine:
                                              C.byref(alive)))
         return done_at, agents, alive.value
 
+    def run_episode(self, L_schedule, policy_mode, use_table=None, table=None, threshold_k=5):
+        """K device-resident steps (small worlds).  Returns (world_alive (K,B) bool, agent_ok (K,B,N) bool)."""
+        Ls = np.ascontiguousarray(L_schedule, dtype=np.float64)
+        K = Ls.shape[0]
+        ut = None if use_table is None else np.ascontiguousarray(use_table, dtype=np.uint8)
+        tb = None if table is None else np.ascontiguousarray(table, dtype=np.int8)
+        if ut is not None and ut.shape != (K,):
+            raise ValueError("use_table must have shape (K,)")
+        if tb is not None and tb.shape != (K, self.B, self.N):
+            raise ValueError(f"table must have shape {(K, self.B, self.N)}")
+        alive = np.zeros((K, self.B), dtype=np.uint8)
+        ok = np.zeros((K, self.B, self.N), dtype=np.uint8)
+        check(self._lib.dw_run_episode(
+            self._h, K, _ffi.ptr_d(Ls), int(policy_mode), _ffi.ptr_u8(ut),
+            None if tb is None else tb.ctypes.data_as(C.POINTER(C.c_int8)), int(threshold_k), _ffi.ptr_u8(alive),
+            _ffi.ptr_u8(ok) if self.N else None))
+        return alive.astype(bool), ok.astype(bool)
+
     # -- plumbing -----------------------------------------------------------------------------
     def set_stream(self, hip_stream_ptr: int):
         check(self._lib.dw_set_stream(self._h, C.c_void_p(hip_stream_ptr)))

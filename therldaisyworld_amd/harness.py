@@ -1,0 +1,111 @@
+"""Episode harnesses on top of the drop-in environment.
+
+``simulate_lifespan(env, agent)`` is the reference's lifespan harness
+(``notebooks/greedy_longevity_abatement.ipynb`` cell 2:28-57): run an episode until every world's
+biosphere is dead and return, per world, the number of steps it was alive and, per agent, the number of
+steps its reward stayed >= 0.1.  Results and legacy-NumPy-RNG consumption are identical to running the
+notebook's loop on the reference.
+
+For small worlds (H*W <= 4096, scripted policy) the loop does not call ``env.step`` per step: whole chunks
+of steps run device-resident (``dw_run_episode``: policy, grazing, physics and the per-step alive flags in
+one launch with the worlds in LDS); the host only draws the policy's random numbers for the chunk in the
+reference's order and post-processes the flags.  If the episode ends inside a chunk the chunk is replayed
+from a snapshot for exactly the remaining steps, so the environment is left in the very state (grid, agents,
+L, step_count, RNG stream) the reference loop would leave it in.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _ffi
+from .agents.greedy import Greedy
+
+LIFESPAN_THRESHOLD_K = 5          # grid_done = max cover <= 0.005 (notebook cell 2:48)
+
+
+def _simulate_on_host(env, agent, obs, done_at, agents_done_at):
+    """The notebook's loop verbatim (any environment / any callable agent)."""
+    while True:
+        action = agent(obs) if agent is not None else None
+        obs, reward, done, info = env.step(action)
+        grid_done = env.grid[:, 1:3, :, :].max(axis=(1, 2, 3)) <= 0.005
+        done_at += (1 - 1 * grid_done)
+        agents_done_at += (1 - 1 * done)
+        if grid_done.mean() == 1.0:
+            return done_at, agents_done_at
+
+
+def _policy_mode(agent):
+    if agent is None:
+        return _ffi.POLICY_ZEROS                      # ref step(None): action 0 for every agent
+    if type(agent) is Greedy:
+        return _ffi.POLICY_ARGMAX if agent.greedy else _ffi.POLICY_ARGMIN
+    return None
+
+
+def _luminosity_schedule(env, nsteps):
+    """L of the next `nsteps` steps, WITHOUT touching env (ref update_L :463-473 replayed on copies)."""
+    L, dL, sc, mn, mx = env.L, env.dL, env.step_count, env.min_L, env.max_L
+    out = []
+    for _ in range(nsteps):
+        out.append(L)
+        sc += 1
+        if env.ramp_up_down and sc % env.ramp_period == 0:
+            dL *= -1
+            mn -= env.ddL
+            mx += env.ddL
+        L += dL
+        L = max([min([L, mx]), mn])
+    return out
+
+
+def simulate_lifespan(env, agent, chunk=32, use_device_loop=True):
+    obs = env.reset()
+    B, N = obs.shape[0], obs.shape[1]
+    done_at = np.zeros((B,), dtype=int)
+    agents_done_at = np.zeros((B, N, 1), dtype=int)
+    mode = _policy_mode(agent)
+    small = env.dim * env.dim <= 4096 and env.precision != "f64" and env.collision_mode == 0
+    if not (use_device_loop and small and mode is not None):
+        return _simulate_on_host(env, agent, obs, done_at, agents_done_at)
+
+    eng = env._engine
+    # step 1 through the ordinary path: the initial state is not quantised (ref initialize_grid)
+    action = agent(obs) if agent is not None else None
+    obs, reward, done, _ = env.step(action)
+    alive = eng.reduce()["max_k"] > LIFESPAN_THRESHOLD_K
+    done_at += alive
+    agents_done_at += (1 - 1 * done)
+    if not alive.any():
+        return done_at, agents_done_at
+
+    while True:
+        K = int(chunk)
+        use_table = np.zeros(K, dtype=np.uint8)
+        table = np.zeros((K, B, N), dtype=np.int8)
+        rng_after = []
+        for t in range(K):                                 # the policy's draws, in the reference's order
+            if agent is not None and not agent.draw_branch():
+                use_table[t] = 1
+                table[t] = agent.draw_random_actions(B, N)[..., 0]
+            rng_after.append(np.random.get_state())
+        Ls = _luminosity_schedule(env, K)
+        snap = (eng.download_planes(), eng.download_agents())
+        alive_k, ok_k = eng.run_episode(Ls, mode, use_table, table, LIFESPAN_THRESHOLD_K)
+        all_dead = ~alive_k.any(axis=1)
+        executed = int(np.argmax(all_dead)) + 1 if all_dead.any() else K
+        done_at += alive_k[:executed].sum(axis=0)
+        agents_done_at += ok_k[:executed].sum(axis=0)[..., None]
+        if executed < K:
+            # the episode ended inside the chunk: replay exactly `executed` steps from the snapshot
+            (light, dark), (idx, st) = snap
+            eng.upload_state_f32(light.astype(np.float32), dark.astype(np.float32), quantised=True)
+            eng.upload_agents(idx, st)
+            eng.run_episode(Ls[:executed], mode, use_table[:executed], table[:executed], LIFESPAN_THRESHOLD_K)
+            np.random.set_state(rng_after[executed - 1])
+        for _ in range(executed):                          # host scalars of the environment
+            env._L_pass = env.L
+            env.L = env.update_L(env.L)
+        env._invalidate()
+        if executed < K:
+            return done_at, agents_done_at
