@@ -534,3 +534,53 @@ def test_c1_trajectory_via_episode_kernel_g2(amd, golden):
         assert np.array_equal(_k(gd).astype(np.uint16), g[f"dark_k_{t}"]), t
     assert L == float(g["final_L"])
     eng.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# temporal fusion (two steps per HBM round trip, float32-only mode)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,H,W", [(3, 256, 256), (2, 100, 256), (1, 70, 320), (1, 130, 516), (2, 64, 1024)])
+@pytest.mark.parametrize("nsteps", [3, 8, 13])
+def test_fused_step_pairs_equal_single_steps(amd, monkeypatch, B, H, W, nsteps):
+    """dw_step_n in fast mode fuses pairs of steps in one kernel (step_stream_fused2): the result must be
+    bit-identical to the same number of ordinary fast steps (rotate and overlapped-strip variants,
+    partial strips, odd counts), the reductions must describe the final state and the retained
+    previous state must be the true predecessor."""
+    outs = []
+    for fuse in (True, False):
+        if fuse:
+            monkeypatch.delenv("DW_NO_FUSE", raising=False)
+        else:
+            monkeypatch.setenv("DW_NO_FUSE", "1")
+        eng = _engine(amd, B, H, W, 0, "fast")
+        assert ("fuses step pairs" in eng.kernel_info()) == fuse
+        eng.init_random(5)
+        L = eng.step_n(nsteps, 0.9, 0.004, 0.75, 1.5)
+        outs.append((L, eng.download_planes(), eng.download_planes(1), eng.reduce(), eng.download_grid()))
+        eng.close()
+    a, b = outs
+    assert a[0] == b[0]
+    assert np.array_equal(a[1][0], b[1][0]) and np.array_equal(a[1][1], b[1][1])
+    assert np.array_equal(a[2][0], b[2][0]) and np.array_equal(a[2][1], b[2][1])
+    for f in ("max_k", "sum_light_k", "sum_dark_k"):
+        assert np.array_equal(a[3][f], b[3][f])
+    assert np.array_equal(a[4], b[4])
+
+
+def test_fused_fast_trajectory_vs_oracle_tolerance(amd):
+    """Fused float32 stepping against the float64 C oracle from the same state: after 2 steps every
+    cell within 2 quanta and >= 99 % identical (each fused step has the single-step fast tolerance)."""
+    B, H, W = 2, 256, 256
+    eng = _engine(amd, B, H, W, 0, "fast")
+    eng.init_random(3)
+    eng.step_n(60, 0.9, 0.002, 0.75, 1.5)            # developed, quantised state
+    light, dark = eng.download_planes()
+    L0 = 1.02
+    L1 = eng.step_n(3, L0, 0.002, 0.75, 1.5)          # fused pair + one single step
+    Lo = c_oracle.step_n(light, dark, L0, 0.002, 3)
+    gl, gd = eng.download_planes()
+    assert L1 == Lo
+    dl, dd = np.abs(_k(gl) - _k(light)), np.abs(_k(gd) - _k(dark))
+    assert dl.max() <= 3 and dd.max() <= 3
+    assert 1.0 - (np.count_nonzero(dl) + np.count_nonzero(dd)) / (2.0 * dl.size) >= 0.985
+    eng.close()

@@ -83,6 +83,8 @@ struct dw_handle {
     // streaming kernel (W >= 256)
     bool use_stream = false;
     StripGeom sgeom{};
+    bool allow_fuse = false;          // float32-only mode on wide grids: dw_step_n fuses pairs of steps
+    FusedGeom fgeom{};
     int* done_at = nullptr;           // [B]
     int* agents_done_at = nullptr;    // [B][N]
     int* n_alive = nullptr;
@@ -215,6 +217,7 @@ static void select_kernel(dw_handle* h) {
     h->tcq = 0;
     h->rpt = 0;
     h->use_stream = false;
+    h->allow_fuse = false;
     if (p.precision == DW_PRECISION_F64) return;
     if (p.width % 4 != 0) return;
     const int Wq = p.width / 4;
@@ -224,15 +227,21 @@ static void select_kernel(dw_handle* h) {
         StripGeom& g = h->sgeom;
         g.B = p.batch; g.H = p.height; g.W = p.width;
         g.SR = p.height < 64 ? p.height : 64;
-        if (const char* e = std::getenv("DW_STRIP_ROWS")) {     // tuning experiments only
-            const int r = std::atoi(e);
-            if (r >= 4 && r <= 64) g.SR = r < p.height ? r : p.height;
-        }
         g.ncs = (p.width + 255) / 256;
         g.nrs = (p.height + g.SR - 1) / g.SR;
         g.nstrips = p.batch * g.nrs * g.ncs;
         g.nwg = (g.nstrips + 3) / 4;
         g.chunk = (g.nwg + 7) / 8;
+        h->allow_fuse = p.precision == DW_PRECISION_FAST && !std::getenv("DW_NO_FUSE");
+        FusedGeom& f = h->fgeom;
+        f.B = p.batch; f.H = p.height; f.W = p.width;
+        f.SR = g.SR;
+        f.cols_per_strip = p.width == 256 ? 256 : 248;
+        f.ncs = (p.width + f.cols_per_strip - 1) / f.cols_per_strip;
+        f.nrs = (p.height + f.SR - 1) / f.SR;
+        f.nstrips = p.batch * f.nrs * f.ncs;
+        f.nwg = (f.nstrips + 3) / 4;
+        f.chunk = (f.nwg + 7) / 8;
         return;
     }
     if (Wq >= 64) {
@@ -378,6 +387,34 @@ static int launch_forward(dw_handle* h, double L) {
     h->cur_quantised = true;
     h->stepped = true;
     h->L_last = L;
+    return DW_OK;
+}
+
+// Two steps (luminosities L1 then L2) in one launch: float32-only mode, wide grids, no agent update in
+// between.  The buffer that held the input now holds the state TWO steps back, so the retained
+// "previous state" is not valid afterwards; dw_step_n always ends with an ordinary single step.
+static int launch_forward_fused2(dw_handle* h, double L1, double L2) {
+    const dw_params& p = h->prm;
+    const int in = h->cur, out = 1 - h->cur;
+    const PhysF32 P1 = derive_f32(p, L1), P2 = derive_f32(p, L2);
+    StatsDev* stats = h->stats2[1 - h->sp];
+    unsigned long long* zero_me = reinterpret_cast<unsigned long long*>(h->stats2[h->sp]);
+    const int zero_n = (int)(h->stats_bytes / sizeof(unsigned long long));
+    const FusedGeom& g = h->fgeom;
+    const dim3 grid((unsigned)g.chunk * 8u);
+    if (p.width == 256)
+        hipLaunchKernelGGL((step_stream_fused2<true>), grid, dim3(256), 0, h->stream, h->L32[in], h->D32[in],
+                           h->L32[out], h->D32[out], g, P1, P2, stats, zero_me, zero_n);
+    else
+        hipLaunchKernelGGL((step_stream_fused2<false>), grid, dim3(256), 0, h->stream, h->L32[in], h->D32[in],
+                           h->L32[out], h->D32[out], g, P1, P2, stats, zero_me, zero_n);
+    HIPCHK(hipGetLastError());
+    h->cur = out;
+    h->sp = 1 - h->sp;
+    h->f64 = F64_NONE;
+    h->cur_quantised = true;
+    h->stepped = false;
+    h->L_last = L2;
     return DW_OK;
 }
 
@@ -841,6 +878,19 @@ int dw_step_n(dw_handle* h, int32_t nsteps, double* L_io, double dL, double min_
             return DW_OK;
         }
     }
+    if (!use_device_actions && h->allow_fuse && h->use_stream && h->have_state) {
+        // float32-only mode on wide grids: pairs of steps share one HBM round trip; the last one or two
+        // steps are ordinary launches so that the retained previous state is the true predecessor
+        while (nsteps - s0 >= 3) {
+            const double L1 = L;
+            L += dL; L = L > max_L ? max_L : L; L = L < min_L ? min_L : L;
+            const double L2 = L;
+            L += dL; L = L > max_L ? max_L : L; L = L < min_L ? min_L : L;
+            int rc = launch_forward_fused2(h, L1, L2);
+            if (rc) return rc;
+            s0 += 2;
+        }
+    }
     for (int s = s0; s < nsteps; ++s) {
         int rc;
         if (use_device_actions) {
@@ -1168,8 +1218,9 @@ int dw_kernel_info(dw_handle* h, char* buf, size_t buflen) {
                  "flight%s, %d strips, grid=%d x 256 threads (4 strips each), XCD-chunked",
                  prec, p.width == 256 ? "rotate" : (p.width % 256 == 0 ? "dpp-old" : "general"), g.SR,
                  p.precision == DW_PRECISION_EXACT ? DW_STREAM_RB_EXACT : DW_STREAM_RB_FAST,
-                 p.precision == DW_PRECISION_EXACT ? ", in-wave float64 fix-up from an LDS queue" : "", g.nstrips,
-                 g.chunk * 8);
+                 p.precision == DW_PRECISION_EXACT ? ", in-wave float64 fix-up from an LDS queue"
+                                                    : (h->allow_fuse ? "; dw_step_n fuses step pairs (step_stream_fused2)" : ""),
+                 g.nstrips, g.chunk * 8);
     } else if (h->tcq) {
         const int TR = (256 / h->tcq) * h->rpt;
         snprintf(buf, buflen,

@@ -831,6 +831,153 @@ void step_stream_exact(const float* __restrict__ inL, const float* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------
+// step_stream_fused2 — TWO consecutive steps per HBM round trip (float32-only mode, no agent
+// update between the steps: dw_step_n on wide grids).  Temporal blocking inside the wave-strip
+// design: as a wave marches down its strip, every new input row yields one row of step-1 results
+// (kept only in a second 3-row register window, never written to memory) and, one row behind it,
+// one row of step-2 results, which is stored.  HBM traffic per cell-update drops to ~8.5 B
+// (measured by PMC, profiles/), and the kernel becomes VALU-bound.
+//
+// Horizontal neighbours of step-1 results come from adjacent lanes by DPP like the inputs do.
+//   ROT (W == 256): the wave spans the whole torus row, all 64 lanes produce output.
+//   OVL (other W):  strips overlap by one lane (4 columns) on each side: lanes 0 and 63 load and
+//                   compute step 1 but only lanes 1..62 (248 columns) produce output; no halo loads.
+// Vertically a strip of SR output rows reads SR+4 input rows and computes SR+2 step-1 rows.
+// ---------------------------------------------------------------------------------------------
+struct FusedGeom {
+    int B, H, W;
+    int SR;                   // output rows per wave-strip
+    int ncs, nrs;             // column / row strips per world
+    int nstrips, nwg, chunk;
+    int cols_per_strip;       // 256 (ROT) or 248 (OVL)
+};
+
+template <bool ROT>
+__global__ __launch_bounds__(256) void step_stream_fused2(const float* __restrict__ inL, const float* __restrict__ inD,
+                                                          float* __restrict__ outL, float* __restrict__ outD,
+                                                          FusedGeom G, PhysF32 P1, PhysF32 P2,
+                                                          StatsDev* __restrict__ stats,
+                                                          unsigned long long* __restrict__ zero_me, int zero_n) {
+    const int bid = blockIdx.x;
+    const int wg = (bid & 7) * G.chunk + (bid >> 3);
+    if (wg >= G.nwg) return;
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    if (wg == 0)
+        for (int i = tid; i < zero_n; i += 256) zero_me[i] = 0ull;
+    const int s = wg * 4 + wv;
+    if (s >= G.nstrips) return;
+    const int spw = G.nrs * G.ncs;
+    const int b = s / spw;
+    const int sw = s - b * spw;
+    const int rs = sw / G.ncs, cs = sw - rs * G.ncs;
+    const int r0 = rs * G.SR;
+    const int nr = min(G.SR, G.H - r0);
+    const size_t woff = (size_t)b * G.H * G.W;
+    // this lane's 4 columns (wrapped) and whether it produces output
+    int col = ROT ? 4 * lane : cs * 248 - 4 + 4 * lane;
+    col = col < 0 ? col + G.W : col;
+    col = col >= G.W ? col - G.W : col;                         // W >= 256 > 252: one wrap suffices
+    const bool writes = ROT ? true : (lane >= 1 && lane <= 62 && cs * 248 + 4 * (lane - 1) < G.W);
+    const float* pL = inL + woff;
+    const float* pD = inD + woff;
+    constexpr int kHalo = ROT ? 0 : 3;                          // lr_neighbours flavour: rotate / plain shift
+
+    auto load_raw = [&](int rr) -> Raw {                        // rr in [r0-2, r0+nr+1], clamped + wrapped
+        rr = min(rr, r0 + nr + 1);
+        rr = rr < 0 ? rr + G.H : rr;
+        rr = rr >= G.H ? rr - G.H : rr;
+        Raw w;
+        w.l = stream_load4(pL + (size_t)rr * G.W + col);
+        w.d = stream_load4(pD + (size_t)rr * G.W + col);
+        w.hl = 0.f; w.hd = 0.f;
+        return w;
+    };
+    auto nbrs = [&](const float4& v, float& a, float& c) {
+        if (kHalo == 0) { a = dpp_mov<kDppWaveRor1>(0.f, v.w); c = dpp_mov<kDppWaveRol1>(0.f, v.x); }
+        else { a = dpp_mov<kDppWaveShr1>(0.f, v.w); c = dpp_mov<kDppWaveShl1>(0.f, v.x); }   // lanes 0/63: unused
+    };
+    auto to_rows4 = [&](const float4& l, const float4& d, Row4& L, Row4& D) {
+        float a, c;
+        nbrs(l, a, c);
+        L = make_row(l, a, c);
+        nbrs(d, a, c);
+        D = make_row(d, a, c);
+    };
+    // one row of the map with coefficient set P: (up, mid, down) -> new float4 pair
+    auto row_map = [&](const PhysF32& P, const Row4& upL, const Row4& miL, const Row4& dnL, const Row4& upD,
+                       const Row4& miD, const Row4& dnD, float4& nl, float4& nd) {
+        float ol[4], od[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float El = miL.h2[i] + (upL.x[i] + dnL.x[i]);
+            const float Cl = upL.h2[i] + dnL.h2[i];
+            const float Ed = miD.h2[i] + (upD.x[i] + dnD.x[i]);
+            const float Cd = upD.h2[i] + dnD.h2[i];
+            const GrowthF32 g = growth_f32(P, miL.x[i], miD.x[i], El, Cl, Ed, Cd);
+            ol[i] = finish_fast(miL.x[i], g.gql);
+            od[i] = finish_fast(miD.x[i], g.gqd);
+        }
+        nl = make_float4(ol[0], ol[1], ol[2], ol[3]);
+        nd = make_float4(od[0], od[1], od[2], od[3]);
+    };
+
+    // windows: IL/ID input rows, SL/SD step-1 rows; slot of row index j (0 = row r0-2) is j % 3
+    Row4 IL[3], ID[3], SL[3], SD[3];
+    {
+        const Raw p0 = load_raw(r0 - 2), p1 = load_raw(r0 - 1), p2 = load_raw(r0);
+        to_rows4(p0.l, p0.d, IL[0], ID[0]);
+        to_rows4(p1.l, p1.d, IL[1], ID[1]);
+        to_rows4(p2.l, p2.d, IL[2], ID[2]);
+    }
+    float acc_max = 0.f, acc_l = 0.f, acc_d = 0.f;
+    // iteration j = 1 .. nr+2: step-1 row j (grid row r0-2+j) from input rows j-1, j, j+1; then, from j = 3
+    // on, output row k = j-3 from step-1 rows j-2, j-1, j
+    auto iter = [&](auto U, int j) {
+        constexpr int u = decltype(U)::value;                  // u == j % 3
+        const Raw nx = load_raw(r0 + j);                       // input row j+2, needed by the NEXT iteration
+        __builtin_amdgcn_sched_barrier(0);
+        float4 l1, d1;
+        row_map(P1, IL[(u + 2) % 3], IL[u], IL[(u + 1) % 3], ID[(u + 2) % 3], ID[u], ID[(u + 1) % 3], l1, d1);
+        to_rows4(l1, d1, SL[u], SD[u]);                        // step-1 row j replaces step-1 row j-3
+        if (j >= 3) {
+            float4 l2, d2;
+            row_map(P2, SL[(u + 1) % 3], SL[(u + 2) % 3], SL[u], SD[(u + 1) % 3], SD[(u + 2) % 3], SD[u], l2, d2);
+            if (writes) {
+                const size_t off = woff + (size_t)(r0 + j - 3) * G.W + col;
+                stream_store4(outL + off, l2);
+                stream_store4(outD + off, d2);
+                acc_l += (l2.x + l2.y) + (l2.z + l2.w);
+                acc_d += (d2.x + d2.y) + (d2.z + d2.w);
+                acc_max = fmaxf(acc_max, fmaxf(fmaxf(fmaxf(l2.x, l2.y), fmaxf(l2.z, l2.w)),
+                                               fmaxf(fmaxf(d2.x, d2.y), fmaxf(d2.z, d2.w))));
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        to_rows4(nx.l, nx.d, IL[(u + 2) % 3], ID[(u + 2) % 3]);   // input row j+2 replaces input row j-1
+    };
+    using U0 = std::integral_constant<int, 0>;
+    using U1 = std::integral_constant<int, 1>;
+    using U2 = std::integral_constant<int, 2>;
+    const int jend = nr + 2;
+    int j = 1;
+    for (; j + 2 <= jend; j += 3) {                             // j % 3 == 1 at the top
+        iter(U1{}, j);
+        iter(U2{}, j + 1);
+        iter(U0{}, j + 2);
+    }
+    if (j <= jend) iter(U1{}, j);
+    if (j + 1 <= jend) iter(U2{}, j + 1);
+
+    const float m = wave_max(acc_max);
+    const float sl = wave_sum(acc_l), sd = wave_sum(acc_d);
+    if (lane == 0) {
+        atomicMax(&stats[b].max_k, (unsigned int)m);
+        atomicAdd(&stats[b].sum_l, (unsigned long long)sl);
+        atomicAdd(&stats[b].sum_d, (unsigned long long)sd);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // episode_small — device-resident episode loop for small worlds (H*W <= 4096: the README sweep's
 // 8x8 grids up to C1's 64x64).  SURVEY.md §8(f) row N1.
 //
