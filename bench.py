@@ -54,6 +54,7 @@ def parse():
     ap.add_argument("--precision", default="exact", choices=["exact", "fast", "f64"])
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-modes", action="store_true", help="skip the extra run in the other arithmetic mode")
     return ap.parse_args()
 
 
@@ -133,62 +134,68 @@ def main():
     B, G, N, desc = WORKLOADS[args.workload]
     if args.worlds:
         B = args.worlds
-    p = amd.default_params(B, G, G, N)
-    p.device = local_rank
-    p.precision = _ffi.PRECISION[args.precision]
-    p.world_offset = rank * B                       # global world ids: the ensemble is one sweep
-    eng = amd.Engine(p)
-    eng.init_random(args.seed)
     min_L, max_L, dL = 0.75, 1.5, 0.75 / 512
-
-    # per-agent policy for the agent workloads: greedy (c3) or greedy/antigreedy/random/half-random by
-    # agent index (c5).  Random actions are drawn on the host and uploaded outside the kernels' way.
-    rng = np.random.RandomState(args.seed + rank)
-
-    def run(nsteps, L):
-        if N == 0:
-            return eng.step_n(nsteps, L, dL, min_L, max_L)
-        for _ in range(nsteps):
-            if args.workload == "c5":
-                eng.policy_greedy(argmin=False)
-                a = eng.download_actions()
-                eng.policy_greedy(argmin=True)
-                a[:, 4:8] = eng.download_actions()[:, 4:8]
-                a[:, 8:12] = rng.randint(9, size=(B, 4))
-                half = rng.rand() > 0.5
-                if not half:
-                    a[:, 12:16] = rng.randint(9, size=(B, 4))
-                eng.upload_actions(a)
-            else:
-                eng.policy_greedy(argmin=False)
-            eng.step_device_actions(L)
-            L = min(max(L + dL, min_L), max_L)
-        return L
-
-    L = run(args.warmup, min_L)
-    eng.sync()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    t0 = time.perf_counter()
-    eng.timer_start()
-    L = run(args.steps, L)
-    ev_ms = eng.timer_stop()                        # HIP events on the kernel's stream (synchronises)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed = ensemble.max_over_ranks(elapsed)
-    ev_ms = ensemble.max_over_ranks(ev_ms)
-
     cells = B * G * G
-    value = cells * args.steps * n_gpus / elapsed
-    kernel_ms = ev_ms / args.steps
-    achieved = BYTES_PER_CELL_UPDATE * cells / (kernel_ms * 1e-3) / 1e9
-    stats = eng.reduce()
-    fixups = eng.last_fixup_count()
+
+    def measure(precision, steps, warmup):
+        """One timed run of `steps` steps in the given arithmetic mode; returns the numbers of the JSON."""
+        p = amd.default_params(B, G, G, N)
+        p.device = local_rank
+        p.precision = _ffi.PRECISION[precision]
+        p.world_offset = rank * B                       # global world ids: the ensemble is one sweep
+        eng = amd.Engine(p)
+        eng.init_random(args.seed)
+        # per-agent policy for the agent workloads: greedy (c3) or greedy/antigreedy/random/half-random by
+        # agent index (c5).  Random actions are drawn on the host and uploaded.
+        rng = np.random.RandomState(args.seed + rank)
+
+        def run(nsteps, L):
+            if N == 0:
+                return eng.step_n(nsteps, L, dL, min_L, max_L)
+            for _ in range(nsteps):
+                if args.workload == "c5":
+                    eng.policy_greedy(argmin=False)
+                    a = eng.download_actions()
+                    eng.policy_greedy(argmin=True)
+                    a[:, 4:8] = eng.download_actions()[:, 4:8]
+                    a[:, 8:12] = rng.randint(9, size=(B, 4))
+                    if not (rng.rand() > 0.5):
+                        a[:, 12:16] = rng.randint(9, size=(B, 4))
+                    eng.upload_actions(a)
+                else:
+                    eng.policy_greedy(argmin=False)
+                eng.step_device_actions(L)
+                L = min(max(L + dL, min_L), max_L)
+            return L
+
+        L = run(warmup, min_L)
+        eng.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        eng.timer_start()
+        L = run(steps, L)
+        ev_ms = eng.timer_stop()                        # HIP events on the kernel's stream (synchronises)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        elapsed = ensemble.max_over_ranks(time.perf_counter() - t0)
+        ev_ms = ensemble.max_over_ranks(ev_ms)
+        kernel_ms = ev_ms / steps
+        achieved = BYTES_PER_CELL_UPDATE * cells / (kernel_ms * 1e-3) / 1e9
+        stats = eng.reduce()
+        res = {"value": cells * steps * n_gpus / elapsed, "ms_per_step": elapsed / steps * 1e3,
+               "kernel_ms": kernel_ms, "achieved": achieved, "frac": achieved / HBM_PEAK_GBS,
+               "fixups": eng.last_fixup_count(), "kernel": eng.kernel_info(), "stats": stats}
+        eng.close()
+        return res
+
+    m = measure(args.precision, args.steps, args.warmup)
+    value, kernel_ms, achieved, fixups, info, stats = (m["value"], m["kernel_ms"], m["achieved"], m["fixups"],
+                                                       m["kernel"], m["stats"])
+    elapsed_ms_per_step = m["ms_per_step"]
     all_stats = ensemble.gather_per_world(stats) if dist is not None else stats   # end-of-run gather (RCCL)
-    info = eng.kernel_info()
 
     out = {
         "metric": "cell-updates/sec (grid x batch), fused stencil+growth step",
@@ -197,11 +204,12 @@ def main():
         "n_gpus": n_gpus,
         "steps": args.steps,
         "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3,
+        "ms_per_step": elapsed_ms_per_step,
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32" if args.precision != "f64" else "f64",
+        "dtype": {"exact": "f32 (+ f64 re-evaluation of near-tie cells: bit-identical to f64)", "fast": "f32",
+                  "f64": "f64"}[args.precision],
         "data": "synthetic (device Philox initial state with the distribution of initialize_grid; ramped luminosity)",
         "config": {"workload": f"{args.workload}: {desc}", "worlds_per_gpu": B, "grid": [G, G], "agents_per_world": N,
                    "precision": args.precision, "kernel": info, "total_worlds": int(all_stats.shape[0]),
@@ -211,13 +219,21 @@ def main():
                      "bytes_per_cell_update": BYTES_PER_CELL_UPDATE, "cells_per_launch": cells,
                      "kernel_ms": kernel_ms, "f64_fixups_last_step": fixups},
     }
+    if not args.no_modes:
+        # the other arithmetic mode on the same workload, for the record (shorter run).  In "fast" mode
+        # dw_step_n fuses pairs of steps into one launch on wide grids without agents (temporal blocking),
+        # so its algorithmic GB/s may exceed the HBM peak; measured HBM bytes are in profiles/.
+        other = "fast" if args.precision == "exact" else "exact"
+        o = measure(other, max(10, args.steps // 2), max(4, args.warmup // 2))
+        out["modes"] = {other: {"value": o["value"], "ms_per_step": o["ms_per_step"], "kernel_ms": o["kernel_ms"],
+                                "achieved_GBps": o["achieved"], "frac": o["frac"], "kernel": o["kernel"],
+                                "traffic": load_traffic(args.workload, other)}}
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(G, p)
+        out["cpu_baseline"] = cpu_baseline(G, None)
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:
         print(json.dumps(out))
-    eng.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
