@@ -541,18 +541,19 @@ def test_c1_trajectory_via_episode_kernel_g2(amd, golden):
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("B,H,W", [(3, 256, 256), (2, 100, 256), (1, 70, 320), (1, 130, 516), (2, 64, 1024)])
 @pytest.mark.parametrize("nsteps", [3, 8, 13])
-def test_fused_step_pairs_equal_single_steps(amd, monkeypatch, B, H, W, nsteps):
-    """dw_step_n in fast mode fuses pairs of steps in one kernel (step_stream_fused2): the result must be
-    bit-identical to the same number of ordinary fast steps (rotate and overlapped-strip variants,
-    partial strips, odd counts), the reductions must describe the final state and the retained
-    previous state must be the true predecessor."""
+@pytest.mark.parametrize("precision", ["fast", "exact"])
+def test_fused_step_pairs_equal_single_steps(amd, monkeypatch, B, H, W, nsteps, precision):
+    """dw_step_n fuses pairs of steps in one kernel (step_stream_fused2[_exact]): the result must be
+    bit-identical to the same number of ordinary steps of the same arithmetic mode (rotate and
+    overlapped-strip variants, partial strips, odd counts), the reductions must describe the final
+    state and the retained previous state must be the true predecessor."""
     outs = []
     for fuse in (True, False):
         if fuse:
             monkeypatch.delenv("DW_NO_FUSE", raising=False)
         else:
             monkeypatch.setenv("DW_NO_FUSE", "1")
-        eng = _engine(amd, B, H, W, 0, "fast")
+        eng = _engine(amd, B, H, W, 0, precision)
         assert ("fuses step pairs" in eng.kernel_info()) == fuse
         eng.init_random(5)
         L = eng.step_n(nsteps, 0.9, 0.004, 0.75, 1.5)
@@ -583,4 +584,41 @@ def test_fused_fast_trajectory_vs_oracle_tolerance(amd):
     dl, dd = np.abs(_k(gl) - _k(light)), np.abs(_k(gd) - _k(dark))
     assert dl.max() <= 3 and dd.max() <= 3
     assert 1.0 - (np.count_nonzero(dl) + np.count_nonzero(dd)) / (2.0 * dl.size) >= 0.985
+    eng.close()
+
+
+@pytest.mark.parametrize("B,H,W", [(3, 256, 256), (1, 70, 320), (2, 64, 1024)])
+def test_fused_exact_trajectory_bit_exact_vs_oracle(amd, B, H, W):
+    """Exact mode with fused step pairs against the float64 C oracle over 41 steps (20 fused launches +
+    the float64 first step from the un-quantised device state): bit-identical planes."""
+    eng = _engine(amd, B, H, W, 0, "exact")
+    assert "step_stream_fused2_exact" in eng.kernel_info()
+    eng.init_random(11)
+    light, dark = eng.download_planes()
+    Lg = eng.step_n(41, 0.85, 0.01, 0.75, 1.5)
+    Lo = c_oracle.step_n(light, dark, 0.85, 0.01, 41)
+    gl, gd = eng.download_planes()
+    assert Lg == Lo
+    assert np.array_equal(_k(gl), _k(light)) and np.array_equal(_k(gd), _k(dark))
+    eng.close()
+
+
+@pytest.mark.parametrize("B,H,W,nsteps", [(2, 256, 256, 7), (1, 70, 320, 6), (2, 64, 128, 3)])
+@pytest.mark.parametrize("qcap,mcap", [(2, 64), (256, 0), (0, 0)])
+def test_exact_mode_overflow_fallbacks_are_exact(amd, monkeypatch, B, H, W, nsteps, qcap, mcap):
+    """Shrink the near-tie queues so that they overflow everywhere: the fallbacks (whole strip / tile
+    recomputed in float64, single-step and fused kernels) must still give the oracle's result."""
+    monkeypatch.setenv("DW_TEST_QUEUE_CAP", str(qcap))
+    monkeypatch.setenv("DW_TEST_MISMATCH_CAP", str(mcap))
+    eng = _engine(amd, B, H, W, 0, "exact")
+    eng.init_random(23)
+    light, dark = eng.download_planes()
+    Lg = eng.step_n(nsteps, 0.95, 0.01, 0.75, 1.5)
+    Lo = c_oracle.step_n(light, dark, 0.95, 0.01, nsteps)
+    gl, gd = eng.download_planes()
+    assert Lg == Lo
+    assert np.array_equal(_k(gl), _k(light)) and np.array_equal(_k(gd), _k(dark))
+    s = eng.reduce()
+    assert np.array_equal(s["sum_light_k"], _k(gl).sum(axis=(1, 2)))
+    assert np.array_equal(s["max_k"], np.maximum(_k(gl).max(axis=(1, 2)), _k(gd).max(axis=(1, 2))))
     eng.close()

@@ -232,7 +232,17 @@ static void select_kernel(dw_handle* h) {
         g.nstrips = p.batch * g.nrs * g.ncs;
         g.nwg = (g.nstrips + 3) / 4;
         g.chunk = (g.nwg + 7) / 8;
-        h->allow_fuse = p.precision == DW_PRECISION_FAST && !std::getenv("DW_NO_FUSE");
+        g.qcap = kWaveQueueCap;
+        int mcap = kMismatchCap;
+        if (const char* e = std::getenv("DW_TEST_QUEUE_CAP")) {  // tests: force the overflow fallbacks
+            const int v = std::atoi(e);
+            if (v >= 0 && v < kWaveQueueCap) g.qcap = v;
+        }
+        if (const char* e = std::getenv("DW_TEST_MISMATCH_CAP")) {
+            const int v = std::atoi(e);
+            if (v >= 0 && v < kMismatchCap) mcap = v;
+        }
+        h->allow_fuse = !std::getenv("DW_NO_FUSE");
         FusedGeom& f = h->fgeom;
         f.B = p.batch; f.H = p.height; f.W = p.width;
         f.SR = g.SR;
@@ -242,6 +252,8 @@ static void select_kernel(dw_handle* h) {
         f.nstrips = p.batch * f.nrs * f.ncs;
         f.nwg = (f.nstrips + 3) / 4;
         f.chunk = (f.nwg + 7) / 8;
+        f.qcap = g.qcap;
+        f.mcap = mcap;
         return;
     }
     if (Wq >= 64) {
@@ -261,6 +273,11 @@ static void select_kernel(dw_handle* h) {
     g.tiles_c = (Wq + h->tcq - 1) / h->tcq;
     g.ntiles = p.batch * g.tiles_r * g.tiles_c;
     g.chunk = (g.ntiles + 7) / 8;
+    g.qcap = kMaxFix;
+    if (const char* e = std::getenv("DW_TEST_QUEUE_CAP")) {      // tests: force the overflow fallbacks
+        const int v = std::atoi(e);
+        if (v >= 0 && v < kMaxFix) g.qcap = v;
+    }
     h->tile_lds = (size_t)2 * (TR + 2) * (h->tcq + 2) * 4 * sizeof(float);
 }
 
@@ -397,20 +414,30 @@ static int launch_forward_fused2(dw_handle* h, double L1, double L2) {
     const dw_params& p = h->prm;
     const int in = h->cur, out = 1 - h->cur;
     const PhysF32 P1 = derive_f32(p, L1), P2 = derive_f32(p, L2);
-    StatsDev* stats = h->stats2[1 - h->sp];
     unsigned long long* zero_me = reinterpret_cast<unsigned long long*>(h->stats2[h->sp]);
     const int zero_n = (int)(h->stats_bytes / sizeof(unsigned long long));
     const FusedGeom& g = h->fgeom;
     const dim3 grid((unsigned)g.chunk * 8u);
-    if (p.width == 256)
-        hipLaunchKernelGGL((step_stream_fused2<true>), grid, dim3(256), 0, h->stream, h->L32[in], h->D32[in],
-                           h->L32[out], h->D32[out], g, P1, P2, stats, zero_me, zero_n);
-    else
-        hipLaunchKernelGGL((step_stream_fused2<false>), grid, dim3(256), 0, h->stream, h->L32[in], h->D32[in],
-                           h->L32[out], h->D32[out], g, P1, P2, stats, zero_me, zero_n);
+    const bool rot = p.width == 256;
+    if (p.precision == DW_PRECISION_EXACT) {
+        const PhysF64 P64 = make_f64(p, L1);
+        if (rot)
+            hipLaunchKernelGGL((step_stream_fused2_exact<true>), grid, dim3(256), 0, h->stream, h->L32[in], h->D32[in],
+                               h->L32[out], h->D32[out], g, P1, P2, P64, L1, L2, zero_me, zero_n);
+        else
+            hipLaunchKernelGGL((step_stream_fused2_exact<false>), grid, dim3(256), 0, h->stream, h->L32[in], h->D32[in],
+                               h->L32[out], h->D32[out], g, P1, P2, P64, L1, L2, zero_me, zero_n);
+    } else {
+        if (rot)
+            hipLaunchKernelGGL((step_stream_fused2<true>), grid, dim3(256), 0, h->stream, h->L32[in], h->D32[in],
+                               h->L32[out], h->D32[out], g, P1, P2, zero_me, zero_n);
+        else
+            hipLaunchKernelGGL((step_stream_fused2<false>), grid, dim3(256), 0, h->stream, h->L32[in], h->D32[in],
+                               h->L32[out], h->D32[out], g, P1, P2, zero_me, zero_n);
+    }
     HIPCHK(hipGetLastError());
     h->cur = out;
-    h->sp = 1 - h->sp;
+    h->sp = 1 - h->sp;            // the kernel cleared the old buffer; the (untouched, zero) other one is "current"
     h->f64 = F64_NONE;
     h->cur_quantised = true;
     h->stepped = false;
@@ -878,7 +905,14 @@ int dw_step_n(dw_handle* h, int32_t nsteps, double* L_io, double dL, double min_
             return DW_OK;
         }
     }
-    if (!use_device_actions && h->allow_fuse && h->use_stream && h->have_state) {
+    if (!use_device_actions && h->allow_fuse && h->use_stream && h->have_state &&
+        (h->prm.precision == DW_PRECISION_FAST || h->prm.precision == DW_PRECISION_EXACT)) {
+        if (h->prm.precision == DW_PRECISION_EXACT && !h->cur_quantised && nsteps - s0 >= 1) {
+            int rc = launch_forward(h, L);       // exact mode: first step from an un-quantised state in float64
+            if (rc) return rc;
+            L += dL; L = L > max_L ? max_L : L; L = L < min_L ? min_L : L;
+            s0 += 1;
+        }
         // float32-only mode on wide grids: pairs of steps share one HBM round trip; the last one or two
         // steps are ordinary launches so that the retained previous state is the true predecessor
         while (nsteps - s0 >= 3) {
@@ -1218,9 +1252,13 @@ int dw_kernel_info(dw_handle* h, char* buf, size_t buflen) {
                  "flight%s, %d strips, grid=%d x 256 threads (4 strips each), XCD-chunked",
                  prec, p.width == 256 ? "rotate" : (p.width % 256 == 0 ? "dpp-old" : "general"), g.SR,
                  p.precision == DW_PRECISION_EXACT ? DW_STREAM_RB_EXACT : DW_STREAM_RB_FAST,
-                 p.precision == DW_PRECISION_EXACT ? ", in-wave float64 fix-up from an LDS queue"
-                                                    : (h->allow_fuse ? "; dw_step_n fuses step pairs (step_stream_fused2)" : ""),
-                 g.nstrips, g.chunk * 8);
+                 p.precision == DW_PRECISION_EXACT ? ", in-wave float64 fix-up from an LDS queue" : "", g.nstrips,
+                 g.chunk * 8);
+        if (h->allow_fuse) {
+            const size_t n = std::strlen(buf);
+            snprintf(buf + n, buflen - n, "; dw_step_n fuses step pairs (step_stream_fused2%s)",
+                     p.precision == DW_PRECISION_EXACT ? "_exact" : "");
+        }
     } else if (h->tcq) {
         const int TR = (256 / h->tcq) * h->rpt;
         snprintf(buf, buflen,

@@ -32,6 +32,7 @@ struct Geom {
     int tiles_r, tiles_c;     // tiles per world
     int ntiles;               // B * tiles_r * tiles_c
     int chunk;                // ceil(ntiles / 8): tiles per XCD
+    int qcap;                 // near-tie LDS queue capacity in use (<= kMaxFix; tests shrink it)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -335,7 +336,7 @@ __global__ __launch_bounds__(256) void step_tiled(const float* __restrict__ inL,
                     for (int i = 0; i < 4; ++i) {
                         if (ties & (1u << i)) {
                             const unsigned int slot = atomicAdd(&s_nfix, 1u);
-                            if (slot < (unsigned)kMaxFix)
+                            if (slot < (unsigned)G.qcap)
                                 s_fix[slot] = make_uint2(((unsigned)(row + 1) << 16) | (unsigned)((cq + 1) * 4 + i),
                                                          (unsigned)ol[i] | ((unsigned)od[i] << 16));
                         }
@@ -363,10 +364,10 @@ __global__ __launch_bounds__(256) void step_tiled(const float* __restrict__ inL,
         __syncthreads();   // all pushes done
         const unsigned int n = s_nfix;
         const unsigned int q = (unsigned)bid % (unsigned)kNumQueues;
-        if (tid == 0) s_base = (n && n <= (unsigned)kMaxFix) ? atomicAdd(&fq.counts[q * 16], n) : 0u;
+        if (tid == 0) s_base = (n && n <= (unsigned)G.qcap) ? atomicAdd(&fq.counts[q * 16], n) : 0u;
         __syncthreads();
         const unsigned int base = s_base;
-        redo = n > (unsigned)kMaxFix || base + n > fq.qcap;       // uniform for the workgroup
+        redo = n > (unsigned)G.qcap || base + n > fq.qcap;        // uniform for the workgroup
         if (!redo) {
             for (unsigned int e = tid; e < n; e += 256) {
                 const uint2 ent = s_fix[e];
@@ -386,7 +387,7 @@ __global__ __launch_bounds__(256) void step_tiled(const float* __restrict__ inL,
             }
         } else if (tid == 0) {
             // the reservation (if any) stays in the queue as garbage: mark it so fixup_cells skips it
-            if (n <= (unsigned)kMaxFix)
+            if (n <= (unsigned)G.qcap)
                 for (unsigned int e = 0; e < n && base + e < fq.qcap; ++e)
                     fq.entries[((size_t)q * fq.qcap + base + e) * 3] = make_uint4(0xffffffffu, 0u, 0u, 0u);
             fq.redo_tiles[atomicAdd(&fq.counts[kNumQueues * 16], 1u)] = t;
@@ -534,6 +535,7 @@ struct StripGeom {
     int nstrips;              // B * nrs * ncs
     int nwg;                  // ceil(nstrips / 4) workgroups of 4 waves
     int chunk;                // ceil(nwg / 8): workgroups per XCD
+    int qcap;                 // near-tie LDS queue capacity in use (<= kWaveQueueCap; tests shrink it)
 };
 
 // streaming accesses of the hot kernel.  The new planes are not read again within the step, so they
@@ -623,7 +625,8 @@ __device__ __forceinline__ void pack3(const Row4& L, const Row4& D, unsigned int
 constexpr int kWaveQueueCap = 256;          // near-tie entries per wave-strip held in LDS (48 B each)
 
 template <int I>
-__device__ __forceinline__ void queue_tie(bool tie, unsigned int& n, uint4* __restrict__ q, int b, int row, int colq,
+__device__ __forceinline__ void queue_tie(bool tie, unsigned int& n, uint4* __restrict__ q, unsigned int cap, int b,
+                                          int row, int colq,
                                           const Row4& upL, const Row4& miL, const Row4& dnL, const Row4& upD,
                                           const Row4& miD, const Row4& dnD, const float* ol, const float* od) {
     const unsigned long long mask = __ballot(tie);
@@ -631,7 +634,7 @@ __device__ __forceinline__ void queue_tie(bool tie, unsigned int& n, uint4* __re
     if (tie) {
         const unsigned int slot = n + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
                                                                 __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-        if (slot < (unsigned)kWaveQueueCap) {
+        if (slot < cap) {
             unsigned int u0, u1, u2, m0, m1, m2, d0, d1, d2;
             pack3<I>(upL, upD, u0, u1, u2);
             pack3<I>(miL, miD, m0, m1, m2);
@@ -737,10 +740,10 @@ __device__ __forceinline__ void stream_body(const float* __restrict__ inL, const
             stream_store4(outD + off, make_float4(od[0], od[1], od[2], od[3]));
         }
         if (EXACT) {
-            queue_tie<0>(tie[0], nq, q, b, r0 + k, colq, upL, miL, dnL, upD, miD, dnD, ol, od);
-            queue_tie<1>(tie[1], nq, q, b, r0 + k, colq, upL, miL, dnL, upD, miD, dnD, ol, od);
-            queue_tie<2>(tie[2], nq, q, b, r0 + k, colq, upL, miL, dnL, upD, miD, dnD, ol, od);
-            queue_tie<3>(tie[3], nq, q, b, r0 + k, colq, upL, miL, dnL, upD, miD, dnD, ol, od);
+            queue_tie<0>(tie[0], nq, q, (unsigned)G.qcap, b, r0 + k, colq, upL, miL, dnL, upD, miD, dnD, ol, od);
+            queue_tie<1>(tie[1], nq, q, (unsigned)G.qcap, b, r0 + k, colq, upL, miL, dnL, upD, miD, dnD, ol, od);
+            queue_tie<2>(tie[2], nq, q, (unsigned)G.qcap, b, r0 + k, colq, upL, miL, dnL, upD, miD, dnD, ol, od);
+            queue_tie<3>(tie[3], nq, q, (unsigned)G.qcap, b, r0 + k, colq, upL, miL, dnL, upD, miD, dnD, ol, od);
         }
     };
     int k = 0;
@@ -764,7 +767,7 @@ __device__ __forceinline__ void stream_body(const float* __restrict__ inL, const
 
     // ---- exact mode: float64 re-evaluation of this wave's queued near-tie cells ----
     if (EXACT) {
-        if (nq <= (unsigned)kWaveQueueCap) {
+        if (nq <= (unsigned)G.qcap) {
             for (unsigned int e = lane; e < nq; e += 64) {
                 const uint4 e0 = q[e * 3], e1 = q[e * 3 + 1], e2 = q[e * 3 + 2];
                 const unsigned int w[9] = {e0.z, e0.w, e1.x, e1.y, e1.z, e1.w, e2.x, e2.y, e2.z};
@@ -850,14 +853,62 @@ struct FusedGeom {
     int ncs, nrs;             // column / row strips per world
     int nstrips, nwg, chunk;
     int cols_per_strip;       // 256 (ROT) or 248 (OVL)
+    int qcap, mcap;           // queue / mismatch-list capacities in use (tests shrink them)
 };
 
-template <bool ROT>
-__global__ __launch_bounds__(256) void step_stream_fused2(const float* __restrict__ inL, const float* __restrict__ inD,
-                                                          float* __restrict__ outL, float* __restrict__ outD,
-                                                          FusedGeom G, PhysF32 P1, PhysF32 P2,
-                                                          StatsDev* __restrict__ stats,
-                                                          unsigned long long* __restrict__ zero_me, int zero_n) {
+// exact two-step value of one cell straight from the input planes, all in float64: nine step-1
+// evaluations (luminosity La) feeding one step-2 evaluation (Lb).  Used only to repair the rare
+// dependents of a float32 step-1 mismatch and as the overflow fallback.
+__device__ inline void exact2_cell(const float* __restrict__ pL, const float* __restrict__ pD, int H, int W, int r,
+                                   int c, const PhysF64& Pa, const PhysF64& Pb, float& kl, float& kd) {
+    unsigned int w2[9];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            int rr = r + a - 1, cc = c + e - 1;
+            rr = rr < 0 ? rr + H : (rr >= H ? rr - H : rr);
+            cc = cc < 0 ? cc + W : (cc >= W ? cc - W : cc);
+            const int ru = rr == 0 ? H - 1 : rr - 1, rd = rr == H - 1 ? 0 : rr + 1;
+            const int cl = cc == 0 ? W - 1 : cc - 1, cr = cc == W - 1 ? 0 : cc + 1;
+            const int rows[3] = {ru, rr, rd}, cols[3] = {cl, cc, cr};
+            unsigned int w1[9];
+#pragma unroll
+            for (int x = 0; x < 3; ++x)
+#pragma unroll
+                for (int y = 0; y < 3; ++y) {
+                    const size_t o = (size_t)rows[x] * W + cols[y];
+                    w1[x * 3 + y] = (unsigned)pL[o] | ((unsigned)pD[o] << 16);
+                }
+            const NewCoverF64 s1 = cell_f64_lean(Pa, w1);
+            w2[a * 3 + e] = (unsigned)dw_round3_k(s1.nl) | ((unsigned)dw_round3_k(s1.nd) << 16);
+        }
+    const NewCoverF64 s2 = cell_f64_lean(Pb, w2);
+    kl = (float)dw_round3_k(s2.nl);
+    kd = (float)dw_round3_k(s2.nd);
+}
+
+constexpr int kMismatchCap = 64;            // float32 step-1 mismatches per wave-strip held in LDS
+
+// EXACT variant (the default mode's dw_step_n on wide grids).  Both steps run in float32 with the
+// per-cell tie test; near-tie cells of BOTH steps are queued in the wave's LDS queue with their 3x3
+// payload (step 1: the inputs; step 2: the float32 step-1 values).  After the strip the same wave
+//   F1  re-evaluates every queued step-1 cell in float64; almost always the float32 value was right
+//       (~97 %); a cell where it was not is a MISMATCH,
+//   F2  re-evaluates every queued step-2 cell in float64 from its payload and patches the output,
+//   F3  for every mismatch recomputes, entirely in float64 from the input planes, the (up to) nine
+//       output cells that depend on it, and patches them (rare: ~0.01 % of cells).
+// A cell's output is therefore the float64 result whenever any float32 rounding on its dependency
+// cone was uncertain.  Queue / mismatch-list overflow: the whole strip is recomputed in float64.
+// Fused launches leave the per-world reductions untouched (dw_step_n always ends with a single step,
+// which recomputes them), they only keep the double-buffer protocol.
+template <bool ROT, bool EXACT>
+__device__ __forceinline__ void fused2_body(const float* __restrict__ inL, const float* __restrict__ inD,
+                                            float* __restrict__ outL, float* __restrict__ outD, const FusedGeom& G,
+                                            const PhysF32& P1, const PhysF32& P2, const PhysF64& P64, double La,
+                                            double Lb, unsigned long long* __restrict__ zero_me, int zero_n) {
+    __shared__ uint4 s_queue[EXACT ? 4 * kWaveQueueCap * 3 : 1];
+    __shared__ unsigned int s_mm[EXACT ? 4 * kMismatchCap : 1];
     const int bid = blockIdx.x;
     const int wg = (bid & 7) * G.chunk + (bid >> 3);
     if (wg >= G.nwg) return;
@@ -866,6 +917,8 @@ __global__ __launch_bounds__(256) void step_stream_fused2(const float* __restric
         for (int i = tid; i < zero_n; i += 256) zero_me[i] = 0ull;
     const int s = wg * 4 + wv;
     if (s >= G.nstrips) return;
+    uint4* q = s_queue + (EXACT ? wv * kWaveQueueCap * 3 : 0);
+    unsigned int* mm = s_mm + (EXACT ? wv * kMismatchCap : 0);
     const int spw = G.nrs * G.ncs;
     const int b = s / spw;
     const int sw = s - b * spw;
@@ -873,14 +926,23 @@ __global__ __launch_bounds__(256) void step_stream_fused2(const float* __restric
     const int r0 = rs * G.SR;
     const int nr = min(G.SR, G.H - r0);
     const size_t woff = (size_t)b * G.H * G.W;
-    // this lane's 4 columns (wrapped) and whether it produces output
-    int col = ROT ? 4 * lane : cs * 248 - 4 + 4 * lane;
+    const int c00 = ROT ? 0 : cs * 248 - 4;                     // grid column of local column 0 (may be -4)
+    int col = c00 + 4 * lane;
     col = col < 0 ? col + G.W : col;
     col = col >= G.W ? col - G.W : col;                         // W >= 256 > 252: one wrap suffices
     const bool writes = ROT ? true : (lane >= 1 && lane <= 62 && cs * 248 + 4 * (lane - 1) < G.W);
+    // which of my four step-1 cells feed an output cell of this wave (exact mode: only their ties matter)
+    bool need1[4] = {true, true, true, true};
+    if (EXACT && !ROT) {
+        const bool wl = __builtin_amdgcn_update_dpp(0, writes ? 1 : 0, kDppWaveShr1, 0xf, 0xf, false) != 0;
+        const bool wr = __builtin_amdgcn_update_dpp(0, writes ? 1 : 0, kDppWaveShl1, 0xf, 0xf, false) != 0;
+        need1[0] = writes || wl;
+        need1[1] = writes;
+        need1[2] = writes;
+        need1[3] = writes || wr;
+    }
     const float* pL = inL + woff;
     const float* pD = inD + woff;
-    constexpr int kHalo = ROT ? 0 : 3;                          // lr_neighbours flavour: rotate / plain shift
 
     auto load_raw = [&](int rr) -> Raw {                        // rr in [r0-2, r0+nr+1], clamped + wrapped
         rr = min(rr, r0 + nr + 1);
@@ -893,7 +955,7 @@ __global__ __launch_bounds__(256) void step_stream_fused2(const float* __restric
         return w;
     };
     auto nbrs = [&](const float4& v, float& a, float& c) {
-        if (kHalo == 0) { a = dpp_mov<kDppWaveRor1>(0.f, v.w); c = dpp_mov<kDppWaveRol1>(0.f, v.x); }
+        if (ROT) { a = dpp_mov<kDppWaveRor1>(0.f, v.w); c = dpp_mov<kDppWaveRol1>(0.f, v.x); }
         else { a = dpp_mov<kDppWaveShr1>(0.f, v.w); c = dpp_mov<kDppWaveShl1>(0.f, v.x); }   // lanes 0/63: unused
     };
     auto to_rows4 = [&](const float4& l, const float4& d, Row4& L, Row4& D) {
@@ -903,10 +965,13 @@ __global__ __launch_bounds__(256) void step_stream_fused2(const float* __restric
         nbrs(d, a, c);
         D = make_row(d, a, c);
     };
-    // one row of the map with coefficient set P: (up, mid, down) -> new float4 pair
+    unsigned int nq = 0;                                        // queued entries of this wave (uniform)
+    // one row of the map with coefficient set P: (up, mid, down) -> new values; exact mode also queues
+    // the near-tie cells (kind 1 = step 1, 2 = step 2; lrow = row index relative to grid row r0-2)
     auto row_map = [&](const PhysF32& P, const Row4& upL, const Row4& miL, const Row4& dnL, const Row4& upD,
-                       const Row4& miD, const Row4& dnD, float4& nl, float4& nd) {
+                       const Row4& miD, const Row4& dnD, float4& nl, float4& nd, int kind, int lrow, const bool* use) {
         float ol[4], od[4];
+        bool tie[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const float El = miL.h2[i] + (upL.x[i] + dnL.x[i]);
@@ -914,12 +979,26 @@ __global__ __launch_bounds__(256) void step_stream_fused2(const float* __restric
             const float Ed = miD.h2[i] + (upD.x[i] + dnD.x[i]);
             const float Cd = upD.h2[i] + dnD.h2[i];
             const GrowthF32 g = growth_f32(P, miL.x[i], miD.x[i], El, Cl, Ed, Cd);
-            ol[i] = finish_fast(miL.x[i], g.gql);
-            od[i] = finish_fast(miD.x[i], g.gqd);
+            if (EXACT) {
+                bool tl, td;
+                ol[i] = finish_exact(P, miL.x[i], g.gql, g.dKl, g.oml, tl);
+                od[i] = finish_exact(P, miD.x[i], g.gqd, g.dKd, g.omd, td);
+                tie[i] = (tl || td) && use[i];
+            } else {
+                ol[i] = finish_fast(miL.x[i], g.gql);
+                od[i] = finish_fast(miD.x[i], g.gqd);
+            }
         }
         nl = make_float4(ol[0], ol[1], ol[2], ol[3]);
         nd = make_float4(od[0], od[1], od[2], od[3]);
+        if (EXACT && __ballot(tie[0] || tie[1] || tie[2] || tie[3]) != 0ull) {
+            queue_tie<0>(tie[0], nq, q, (unsigned)G.qcap, kind, lrow, 4 * lane, upL, miL, dnL, upD, miD, dnD, ol, od);
+            queue_tie<1>(tie[1], nq, q, (unsigned)G.qcap, kind, lrow, 4 * lane, upL, miL, dnL, upD, miD, dnD, ol, od);
+            queue_tie<2>(tie[2], nq, q, (unsigned)G.qcap, kind, lrow, 4 * lane, upL, miL, dnL, upD, miD, dnD, ol, od);
+            queue_tie<3>(tie[3], nq, q, (unsigned)G.qcap, kind, lrow, 4 * lane, upL, miL, dnL, upD, miD, dnD, ol, od);
+        }
     };
+    const bool use2[4] = {writes, writes, writes, writes};
 
     // windows: IL/ID input rows, SL/SD step-1 rows; slot of row index j (0 = row r0-2) is j % 3
     Row4 IL[3], ID[3], SL[3], SD[3];
@@ -929,27 +1008,23 @@ __global__ __launch_bounds__(256) void step_stream_fused2(const float* __restric
         to_rows4(p1.l, p1.d, IL[1], ID[1]);
         to_rows4(p2.l, p2.d, IL[2], ID[2]);
     }
-    float acc_max = 0.f, acc_l = 0.f, acc_d = 0.f;
     // iteration j = 1 .. nr+2: step-1 row j (grid row r0-2+j) from input rows j-1, j, j+1; then, from j = 3
-    // on, output row k = j-3 from step-1 rows j-2, j-1, j
+    // on, output row k = j-3 (local row j-1) from step-1 rows j-2, j-1, j
     auto iter = [&](auto U, int j) {
         constexpr int u = decltype(U)::value;                  // u == j % 3
         const Raw nx = load_raw(r0 + j);                       // input row j+2, needed by the NEXT iteration
         __builtin_amdgcn_sched_barrier(0);
         float4 l1, d1;
-        row_map(P1, IL[(u + 2) % 3], IL[u], IL[(u + 1) % 3], ID[(u + 2) % 3], ID[u], ID[(u + 1) % 3], l1, d1);
+        row_map(P1, IL[(u + 2) % 3], IL[u], IL[(u + 1) % 3], ID[(u + 2) % 3], ID[u], ID[(u + 1) % 3], l1, d1, 1, j, need1);
         to_rows4(l1, d1, SL[u], SD[u]);                        // step-1 row j replaces step-1 row j-3
         if (j >= 3) {
             float4 l2, d2;
-            row_map(P2, SL[(u + 1) % 3], SL[(u + 2) % 3], SL[u], SD[(u + 1) % 3], SD[(u + 2) % 3], SD[u], l2, d2);
+            row_map(P2, SL[(u + 1) % 3], SL[(u + 2) % 3], SL[u], SD[(u + 1) % 3], SD[(u + 2) % 3], SD[u], l2, d2, 2, j - 1,
+                    use2);
             if (writes) {
                 const size_t off = woff + (size_t)(r0 + j - 3) * G.W + col;
                 stream_store4(outL + off, l2);
                 stream_store4(outD + off, d2);
-                acc_l += (l2.x + l2.y) + (l2.z + l2.w);
-                acc_d += (d2.x + d2.y) + (d2.z + d2.w);
-                acc_max = fmaxf(acc_max, fmaxf(fmaxf(fmaxf(l2.x, l2.y), fmaxf(l2.z, l2.w)),
-                                               fmaxf(fmaxf(d2.x, d2.y), fmaxf(d2.z, d2.w))));
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -968,13 +1043,118 @@ __global__ __launch_bounds__(256) void step_stream_fused2(const float* __restric
     if (j <= jend) iter(U1{}, j);
     if (j + 1 <= jend) iter(U2{}, j + 1);
 
-    const float m = wave_max(acc_max);
-    const float sl = wave_sum(acc_l), sd = wave_sum(acc_d);
-    if (lane == 0) {
-        atomicMax(&stats[b].max_k, (unsigned int)m);
-        atomicAdd(&stats[b].sum_l, (unsigned long long)sl);
-        atomicAdd(&stats[b].sum_d, (unsigned long long)sd);
+    if (EXACT) {
+        PhysF64 Pa = P64, Pb = P64;
+        Pa.L = La;
+        Pb.L = Lb;
+        // grid coordinates of a local (row, column)
+        auto grid_rc = [&](int lrow, int lc, int& gr, int& gc) {
+            gr = r0 - 2 + lrow;
+            gr = gr < 0 ? gr + G.H : (gr >= G.H ? gr - G.H : gr);
+            gc = c00 + lc;
+            gc = gc < 0 ? gc + G.W : (gc >= G.W ? gc - G.W : gc);
+        };
+        // is local (row, column) an output cell of this wave?
+        auto is_output = [&](int lrow, int lc) -> bool {
+            if (lrow < 2 || lrow > nr + 1) return false;
+            if (ROT) return true;
+            const int ln = lc >> 2;
+            return lc >= 4 && lc < 252 && cs * 248 + 4 * (ln - 1) < G.W;
+        };
+        unsigned int nmm = 0;
+        bool redo = nq > (unsigned)G.qcap;
+        if (!redo) {
+            // F1: queued step-1 cells -> mismatch list
+            for (unsigned int base = 0; base < nq; base += 64) {
+                const unsigned int e = base + lane;
+                bool mism = false;
+                unsigned int where = 0;
+                if (e < nq) {
+                    const uint4 e0 = q[e * 3], e1 = q[e * 3 + 1], e2 = q[e * 3 + 2];
+                    if (e0.x == 1u) {
+                        const unsigned int w[9] = {e0.z, e0.w, e1.x, e1.y, e1.z, e1.w, e2.x, e2.y, e2.z};
+                        const NewCoverF64 o = cell_f64_lean(Pa, w);
+                        const unsigned int exact = (unsigned)dw_round3_k(o.nl) | ((unsigned)dw_round3_k(o.nd) << 16);
+                        mism = exact != e2.w;
+                        where = e0.y;
+                    }
+                }
+                const unsigned long long mask = __ballot(mism);
+                if (mism) {
+                    const unsigned int slot = nmm + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                                             __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                    if (slot < (unsigned)G.mcap) mm[slot] = where;
+                }
+                nmm += (unsigned)__popcll(mask);
+            }
+            redo = nmm > (unsigned)G.mcap;
+        }
+        if (!redo) {
+            // F2: queued step-2 cells (their payload holds float32 step-1 values; cells next to a mismatch
+            // are overwritten by F3 below)
+            for (unsigned int e = lane; e < nq; e += 64) {
+                const uint4 e0 = q[e * 3], e1 = q[e * 3 + 1], e2 = q[e * 3 + 2];
+                if (e0.x != 2u) continue;
+                const unsigned int w[9] = {e0.z, e0.w, e1.x, e1.y, e1.z, e1.w, e2.x, e2.y, e2.z};
+                const NewCoverF64 o = cell_f64_lean(Pb, w);
+                int gr, gc;
+                grid_rc((int)(e0.y >> 16), (int)(e0.y & 0xffffu), gr, gc);
+                const size_t off = woff + (size_t)gr * G.W + gc;
+                outL[off] = (float)dw_round3_k(o.nl);
+                outD[off] = (float)dw_round3_k(o.nd);
+            }
+            // F3: the nine dependents of every step-1 mismatch, entirely in float64 from the inputs
+            for (unsigned int pidx = lane; pidx < nmm * 9u; pidx += 64) {
+                const unsigned int m = pidx / 9u, t = pidx - m * 9u;
+                const unsigned int where = mm[m];
+                int lrow = (int)(where >> 16) + (int)(t / 3u) - 1;
+                int lc = (int)(where & 0xffffu) + (int)(t % 3u) - 1;
+                if (ROT) lc = (lc + 256) & 255;
+                if (!is_output(lrow, lc)) continue;
+                int gr, gc;
+                grid_rc(lrow, lc, gr, gc);
+                float kl, kd;
+                exact2_cell(pL, pD, G.H, G.W, gr, gc, Pa, Pb, kl, kd);
+                const size_t off = woff + (size_t)gr * G.W + gc;
+                outL[off] = kl;
+                outD[off] = kd;
+            }
+        } else {
+            // overflow fallback: every output cell of the strip, two float64 steps from the inputs
+            const int ncol = ROT ? 256 : 248;
+            for (int i = lane; i < nr * ncol; i += 64) {
+                const int lrow = 2 + i / ncol, lc = (ROT ? 0 : 4) + i % ncol;
+                if (!is_output(lrow, lc)) continue;
+                int gr, gc;
+                grid_rc(lrow, lc, gr, gc);
+                float kl, kd;
+                exact2_cell(pL, pD, G.H, G.W, gr, gc, Pa, Pb, kl, kd);
+                const size_t off = woff + (size_t)gr * G.W + gc;
+                outL[off] = kl;
+                outD[off] = kd;
+            }
+        }
     }
+}
+
+template <bool ROT>
+__global__ __launch_bounds__(256) void step_stream_fused2(const float* __restrict__ inL, const float* __restrict__ inD,
+                                                          float* __restrict__ outL, float* __restrict__ outD,
+                                                          FusedGeom G, PhysF32 P1, PhysF32 P2,
+                                                          unsigned long long* __restrict__ zero_me, int zero_n) {
+    PhysF64 dummy{};
+    fused2_body<ROT, false>(inL, inD, outL, outD, G, P1, P2, dummy, 0.0, 0.0, zero_me, zero_n);
+}
+
+#ifndef DW_FUSED_EXACT_WAVES
+#define DW_FUSED_EXACT_WAVES 2
+#endif
+template <bool ROT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DW_FUSED_EXACT_WAVES, DW_FUSED_EXACT_WAVES)))
+void step_stream_fused2_exact(const float* __restrict__ inL, const float* __restrict__ inD, float* __restrict__ outL,
+                              float* __restrict__ outD, FusedGeom G, PhysF32 P1, PhysF32 P2, PhysF64 P64, double La,
+                              double Lb, unsigned long long* __restrict__ zero_me, int zero_n) {
+    fused2_body<ROT, true>(inL, inD, outL, outD, G, P1, P2, P64, La, Lb, zero_me, zero_n);
 }
 
 // ---------------------------------------------------------------------------------------------
