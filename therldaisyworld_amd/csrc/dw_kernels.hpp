@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void step_generic(const InT* __restrict__ inL,
             const float Ed = (DW_AT(pd, ru, c) + DW_AT(pd, rd, c)) + (DW_AT(pd, r, cl) + DW_AT(pd, r, cr));
             const float Cd = (DW_AT(pd, ru, cl) + DW_AT(pd, rd, cl)) + (DW_AT(pd, ru, cr) + DW_AT(pd, rd, cr));
 #undef DW_AT
-            const GrowthF32 g = growth_f32(P, li, di, El, Cl, Ed, Cd);
+            const GrowthF32 g = growth_f32<PREC != 1>(P, li, di, El, Cl, Ed, Cd);
             if (PREC == 1) {
                 kl = finish_fast(li, g.gql);
                 kd = finish_fast(di, g.gqd);
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256) void step_tiled(const float* __restrict__ inL,
 #ifdef DW_TUNING
                     if (g_ablate == 1) { ol[i] = El + Cl; od[i] = Ed + Cd; continue; }
 #endif
-                    const GrowthF32 g = growth_f32(P, miL.x[i], miD.x[i], El, Cl, Ed, Cd);
+                    const GrowthF32 g = growth_f32<EXACT>(P, miL.x[i], miD.x[i], El, Cl, Ed, Cd);
                     if (EXACT) {
                         bool tl, td;
                         ol[i] = finish_exact(P, miL.x[i], g.gql, g.dKl, g.oml, tl);
@@ -720,7 +720,7 @@ __device__ __forceinline__ void stream_body(const float* __restrict__ inL, const
             const float Cl = upL.h2[i] + dnL.h2[i];
             const float Ed = miD.h2[i] + (upD.x[i] + dnD.x[i]);
             const float Cd = upD.h2[i] + dnD.h2[i];
-            const GrowthF32 g = growth_f32(P, miL.x[i], miD.x[i], El, Cl, Ed, Cd);
+            const GrowthF32 g = growth_f32<EXACT>(P, miL.x[i], miD.x[i], El, Cl, Ed, Cd);
             if (EXACT) {
                 bool tl, td;
                 ol[i] = finish_exact(P, miL.x[i], g.gql, g.dKl, g.oml, tl);
@@ -978,7 +978,7 @@ __device__ __forceinline__ void fused2_body(const float* __restrict__ inL, const
             const float Cl = upL.h2[i] + dnL.h2[i];
             const float Ed = miD.h2[i] + (upD.x[i] + dnD.x[i]);
             const float Cd = upD.h2[i] + dnD.h2[i];
-            const GrowthF32 g = growth_f32(P, miL.x[i], miD.x[i], El, Cl, Ed, Cd);
+            const GrowthF32 g = growth_f32<EXACT>(P, miL.x[i], miD.x[i], El, Cl, Ed, Cd);
             if (EXACT) {
                 bool tl, td;
                 ol[i] = finish_exact(P, miL.x[i], g.gql, g.dKl, g.oml, tl);
@@ -1304,7 +1304,7 @@ __global__ __launch_bounds__(256) void episode_small(EpisodeIO io, int B, int N,
                 const float Cl = (curL[ru + cl] + curL[rd + cl]) + (curL[ru + cr] + curL[rd + cr]);
                 const float Ed = (curD[ru + cc] + curD[rd + cc]) + (curD[rm + cl] + curD[rm + cr]);
                 const float Cd = (curD[ru + cl] + curD[rd + cl]) + (curD[ru + cr] + curD[rd + cr]);
-                const GrowthF32 g = growth_f32(P, li, di, El, Cl, Ed, Cd);
+                const GrowthF32 g = growth_f32<EXACT>(P, li, di, El, Cl, Ed, Cd);
                 float kl, kd;
                 if (EXACT) {
                     bool tl, td;

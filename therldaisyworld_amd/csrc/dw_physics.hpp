@@ -169,19 +169,32 @@ struct GrowthF32 {
 };
 
 // El/Cl: sums of the 4 edge / 4 corner neighbours of light; Ed/Cd of dark; li/di the centre.
+// SPLIT = true: hi/lo coefficient chains (exact mode: its tie bound relies on the exact hi chain).
+// SPLIT = false: one float32 coefficient each (float32-only mode: 6 instructions fewer per cell).
+template <bool SPLIT = true>
 __device__ __forceinline__ GrowthF32 growth_f32(const PhysF32& P, float li, float di, float El,
                                                 float Cl, float Ed, float Cd) {
     const float Sl8 = El + Cl, Sd8 = Ed + Cd;
-    float hi = P.a1h * Sl8;
-    hi = fmaf(P.a2h, Sd8, hi);
-    hi = fmaf(P.a3h, li, hi);
-    hi = fmaf(P.a4h, di, hi);
-    float lo = P.a1l * Sl8;
-    lo = fmaf(P.a2l, Sd8, lo);
-    lo = fmaf(P.a3l, li, lo);
-    lo = fmaf(P.a4l, di, lo);
-    const float el = (hi + P.c0lh) + (lo + P.c0ll);
-    const float ed = (hi + P.c0dh) + (lo + P.c0dl);
+    float el, ed;
+    if (SPLIT) {
+        float hi = P.a1h * Sl8;
+        hi = fmaf(P.a2h, Sd8, hi);
+        hi = fmaf(P.a3h, li, hi);
+        hi = fmaf(P.a4h, di, hi);
+        float lo = P.a1l * Sl8;
+        lo = fmaf(P.a2l, Sd8, lo);
+        lo = fmaf(P.a3l, li, lo);
+        lo = fmaf(P.a4l, di, lo);
+        el = (hi + P.c0lh) + (lo + P.c0ll);
+        ed = (hi + P.c0dh) + (lo + P.c0dl);
+    } else {
+        float base = (P.a1h + P.a1l) * Sl8;                 // coefficient sums are wave-uniform (hoisted)
+        base = fmaf(P.a2h + P.a2l, Sd8, base);
+        base = fmaf(P.a3h + P.a3l, li, base);
+        base = fmaf(P.a4h + P.a4l, di, base);
+        el = base + (P.c0lh + P.c0ll);
+        ed = base + (P.c0dh + P.c0dl);
+    }
     // light
     const float sl = __builtin_amdgcn_sqrtf(1.0f + el);
     const float yl = __builtin_amdgcn_sqrtf(sl);
