@@ -211,6 +211,15 @@ int dw_reduce(dw_handle* h, dw_world_stats* per_world /* [B] */);
  * dw_upload_actions. */
 int dw_policy_greedy(dw_handle* h, int mode);
 
+/* Learned policy on the device (ref MLP.get_action, daisy/agents/mlp.py:97-116):
+ * the 63 -> 16 -> 32 -> 9 ReLU network evaluated in float64 on the current observations of agents
+ * [agent_begin, agent_end) of every world; argmax of the logits goes to the device action buffer.
+ * params: host float64[1808], the three weight matrices raveled row-major in layer order (ref
+ * get_parameters :118-125).  Two calls with the two halves of the agents reproduce the agent /
+ * adversary split of sges.get_fitness (daisy/evo/sges.py:163-168). */
+int dw_policy_mlp(dw_handle* h, const double* params, int32_t n_params, int32_t agent_begin, int32_t agent_end,
+                  double L_init);
+
 /* Device-resident lifespan harness (ref notebooks/greedy_longevity_abatement.ipynb cell 2:28-57):
  * accumulate done_at[b] += (max_k > threshold_k) and agents_done_at[b][n] += !(done) after each
  * step, on the device.  dw_lifespan_reset zeroes them. */

@@ -429,3 +429,34 @@ def simulate_lifespan(env, agent, max_steps=100000):
         if grid_done.mean() == 1.0:
             break
     return done_at, agents_done_at
+
+
+# ----------------------------------------------------------------------------------------------
+# MLP policy  (ref: daisy/agents/mlp.py:12-146) — SURVEY.md §8(f) row N3
+# ----------------------------------------------------------------------------------------------
+class OracleMLP:
+    """63 -> 16 -> 32 -> 9 ReLU network on the flattened (7,3,3) observation, action = argmax of the
+    logits (ref mlp.py:97-116).  Parameters are one flat float64 vector: the three weight matrices
+    raveled row-major in layer order (ref get_parameters :118-125 / set_parameters :127-144)."""
+
+    IN, H, OUT = 63, (16, 32), 9
+
+    def __init__(self, parameters):
+        shapes = [self.IN, *self.H, self.OUT]
+        self.layers, start = [], 0
+        for a, b in zip(shapes[:-1], shapes[1:]):
+            self.layers.append(np.asarray(parameters[start:start + a * b], dtype=np.float64).reshape(a, b))
+            start += a * b
+        assert start == len(parameters) == 1808
+
+    def forward(self, x):
+        for layer in self.layers[:-1]:
+            x = np.matmul(x, layer)
+            x = x * (x > 0.0)
+        return np.matmul(x, self.layers[-1])
+
+    def get_action(self, obs):
+        x = obs.reshape(*obs.shape[:-3], self.IN)
+        return np.argmax(self.forward(x), axis=-1, keepdims=True)
+
+    __call__ = get_action

@@ -303,10 +303,37 @@ def g9_ctor_rng_order():
     save("G9_ctor_rng_order", **out)
 
 
+def g10_mlp():
+    """MLP policy (daisy/agents/mlp.py): seeded Glorot parameters, actions on real observations, and a
+    get_fitness-style rollout (first half of the agents driven by one net, second half by another;
+    daisy/evo/sges.py:144-181)."""
+    from daisy.agents.mlp import MLP
+    np.random.seed(4242)
+    agent, adversary = MLP(), MLP()
+    pa, pb = agent.get_parameters(), adversary.get_parameters()
+    env = RLDaisyWorld(grid_dimension=8, n_agents=4)
+    env.batch_size = 6
+    obs = env.reset()
+    out = {"params_agent": pa, "params_adversary": pb, "obs0": obs.copy(), "action0": agent(obs),
+           "light0": env.grid[:, 1].copy(), "dark0": env.grid[:, 2].copy(),
+           "agent_indices0": env.agent_indices.copy()}
+    half = obs.shape[1] // 2
+    acts, rewards, dones, obss = [], [], [], []
+    sum_reward = 0.0
+    for t in range(40):
+        a = np.append(agent.get_action(obs[:, :half]), adversary.get_action(obs[:, half:]), axis=1)
+        obs, reward, done, _ = env.step(a)
+        acts.append(a.copy()); rewards.append(reward.copy()); dones.append(done.copy()); obss.append(obs.copy())
+        sum_reward += (reward[:, :half]).mean()
+    out.update(actions=np.array(acts), rewards=np.array(rewards), dones=np.array(dones), obs=np.array(obss),
+               sum_reward=np.float64(sum_reward), grid_final=env.grid.copy())
+    save("G10_mlp", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
     fns = {"g1": g1_forward, "g2": g2_c1_trajectory, "g3": g3_agents, "g4": g4_greedy,
            "g5": g5_lifespans, "g6": g6_ft_convolve, "g7": g7_no_agents, "g8": g8_collisions,
-           "g9": g9_ctor_rng_order}
+           "g9": g9_ctor_rng_order, "g10": g10_mlp}
     for w in which:
         fns[w]()

@@ -175,3 +175,22 @@ def test_action_marshalling():
         Engine._actions(np.array([[[0.5]]]))
     with pytest.raises(ValueError):
         Engine._actions(np.zeros(3))
+
+
+def test_host_mlp_mirror_matches_reference_fixture_g10(golden):
+    """Host mirror of the MLP policy: same Glorot draws (np.random.randn order) and same actions."""
+    from therldaisyworld_amd import MLP
+    g = golden("G10_mlp")
+    np.random.seed(4242)
+    agent, adversary = MLP(), MLP()
+    assert np.array_equal(agent.get_parameters(), g["params_agent"])
+    assert np.array_equal(adversary.get_parameters(), g["params_adversary"])
+    assert np.array_equal(agent(g["obs0"]), g["action0"])
+    half = 2
+    for t in range(1, 40):
+        obs = g["obs"][t - 1]
+        a = np.append(agent.get_action(obs[:, :half]), adversary.get_action(obs[:, half:]), axis=1)
+        assert np.array_equal(a, g["actions"][t])
+    clone = MLP()
+    clone._apply_config(agent.make_config())
+    assert np.array_equal(clone.get_parameters(), agent.get_parameters())

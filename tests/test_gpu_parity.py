@@ -622,3 +622,57 @@ def test_exact_mode_overflow_fallbacks_are_exact(amd, monkeypatch, B, H, W, nste
     assert np.array_equal(s["sum_light_k"], _k(gl).sum(axis=(1, 2)))
     assert np.array_equal(s["max_k"], np.maximum(_k(gl).max(axis=(1, 2)), _k(gd).max(axis=(1, 2))))
     eng.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# MLP policy on the device
+# ---------------------------------------------------------------------------------------------
+def test_mlp_policy_on_device_matches_reference_fixture_g10(amd, golden):
+    """The 63-16-32-9 network evaluated by the policy_mlp kernel from device-resident observations:
+    same actions as the reference's MLP on every step of a 40-step agent/adversary rollout, same
+    rewards, same final grid; the host mirror gives the same actions from NumPy observations."""
+    g = golden("G10_mlp")
+    np.random.seed(4242)
+    agent, adversary = amd.MLP(), amd.MLP()                 # same Glorot draws as the reference's MLP()
+    assert np.array_equal(agent.get_parameters(), g["params_agent"])
+    assert np.array_equal(adversary.get_parameters(), g["params_adversary"])
+    env = amd.RLDaisyWorld(grid_dimension=8, n_agents=4)
+    env.batch_size = 6
+    obs = env.reset()
+    np.testing.assert_allclose(obs, g["obs0"], rtol=1e-12, atol=0)
+    assert np.array_equal(agent(obs), g["action0"])         # host mirror
+    agent.act_on_device(env)
+    assert np.array_equal(env._engine.download_actions()[..., None], g["action0"])
+    half, sum_reward = 2, 0.0
+    for t in range(40):
+        agent.act_on_device(env, 0, half)
+        adversary.act_on_device(env, half, 4)
+        dev_actions = env._engine.download_actions()[..., None]
+        assert np.array_equal(dev_actions, g["actions"][t]), t
+        obs, reward, done, _ = env.step(dev_actions)
+        assert np.array_equal(obs, g["obs"][t]), t
+        assert np.array_equal(reward, g["rewards"][t]) and np.array_equal(done, g["dones"][t]), t
+        sum_reward += reward[:, :half].mean()
+    assert sum_reward == float(g["sum_reward"])
+    assert np.array_equal(env.grid, g["grid_final"])
+    env.close()
+
+
+def test_get_fitness_harness_matches_reference_rollout_g10(amd, golden):
+    from therldaisyworld_amd.harness import get_fitness
+    g = golden("G10_mlp")
+    np.random.seed(4242)
+    agent, adversary = amd.MLP(), amd.MLP()
+    env = amd.RLDaisyWorld(grid_dimension=8, n_agents=4)
+    env.batch_size = 6
+    # get_fitness resets the environment itself: rewind the stream to where the fixture's reset started
+    np.random.seed(4242)
+    amd.MLP(), amd.MLP()
+    env2 = amd.RLDaisyWorld(grid_dimension=8, n_agents=4)   # consumes the constructor's draws again
+    env2.batch_size = 6
+    fitness, total_steps, done_at = get_fitness(env2, agent, adversary, max_steps=40)
+    assert fitness == float(g["sum_reward"]) / (6 * 4)
+    assert np.array_equal(np.array(done_at), (1 - 1 * g["dones"]).sum(axis=0))
+    assert np.array_equal(total_steps, (1 - 1 * g["dones"]).sum(axis=0))
+    assert np.array_equal(env2.grid, g["grid_final"])
+    env.close(); env2.close()

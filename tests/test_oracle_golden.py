@@ -235,3 +235,24 @@ def test_c_oracle_matches_numpy_oracle_multiworld():
     ref = env.forward(grid)
     out = c_oracle.forward(light, dark, 1.03)
     assert np.array_equal(out, ref)
+
+
+def test_g10_mlp_policy(golden):
+    g = golden("G10_mlp")
+    agent, adversary = O.OracleMLP(g["params_agent"]), O.OracleMLP(g["params_adversary"])
+    assert np.array_equal(agent(g["obs0"]), g["action0"])
+    env = _env(8, 4, 6)
+    env.set_initial_cover(g["light0"], g["dark0"])
+    env.agent_indices = g["agent_indices0"].copy()
+    env.agent_states = np.ones((6, 4, 1))
+    obs = env.get_obs(env.agent_indices)
+    np.testing.assert_allclose(obs, g["obs0"], rtol=1e-12, atol=0)
+    half, sum_reward = 2, 0.0
+    for t in range(40):
+        a = np.append(agent.get_action(obs[:, :half]), adversary.get_action(obs[:, half:]), axis=1)
+        assert np.array_equal(a, g["actions"][t]), t
+        obs, reward, done, _ = env.step(a)
+        assert np.array_equal(obs, g["obs"][t]) and np.array_equal(reward, g["rewards"][t])
+        sum_reward += reward[:, :half].mean()
+    assert sum_reward == float(g["sum_reward"])
+    assert np.array_equal(env.grid, g["grid_final"])

@@ -8,5 +8,6 @@ an environment does (there is no CPU fallback).
 from .daisy_world_rl import RLDaisyWorld  # noqa: F401
 from .engine import Engine, default_params  # noqa: F401
 from .agents.greedy import Greedy  # noqa: F401
+from .agents.mlp import MLP  # noqa: F401
 
-__all__ = ["RLDaisyWorld", "Engine", "default_params", "Greedy"]
+__all__ = ["RLDaisyWorld", "Engine", "default_params", "Greedy", "MLP"]

@@ -77,6 +77,7 @@ SIGNATURES = {
     "dw_get_reward_done": (C.c_int, [_vp, _pd, _pu8]),
     "dw_reduce": (C.c_int, [_vp, C.POINTER(DwWorldStats)]),
     "dw_policy_greedy": (C.c_int, [_vp, C.c_int]),
+    "dw_policy_mlp": (C.c_int, [_vp, _pd, _i32, _i32, _i32, _dbl]),
     "dw_lifespan_reset": (C.c_int, [_vp]),
     "dw_lifespan_accumulate": (C.c_int, [_vp, _u32]),
     "dw_lifespan_download": (C.c_int, [_vp, _pi, _pi, _pi]),

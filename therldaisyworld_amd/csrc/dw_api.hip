@@ -1075,6 +1075,62 @@ int dw_policy_greedy(dw_handle* h, int mode) {
     return DW_OK;
 }
 
+// fills h->scratch with the [B][N][63] observations of the current state (device side of dw_get_obs)
+static int observe_into_scratch(dw_handle* h, double L_init, size_t extra_bytes) {
+    const dw_params& p = h->prm;
+    const size_t bn = (size_t)p.batch * p.n_agents;
+    int rc = ensure_scratch(h, sizeof(double) * bn * 63 + extra_bytes);
+    if (rc) return rc;
+    const int threads = (int)(bn * 9);
+    const dim3 g((threads + 127) / 128);
+    const int cur = h->cur, prev = 1 - h->cur;
+    if (h->stepped) {
+        const PhysF64 P = make_f64(p, h->L_last);
+        if (h->f64 == F64_PREV)
+            hipLaunchKernelGGL((observe<double, true>), g, dim3(128), 0, h->stream, h->L64, h->D64, h->L32[cur],
+                               h->D32[cur], h->idx, h->st, p.batch, p.n_agents, p.height, p.width, P, p.obs_mask,
+                               h->scratch);
+        else
+            hipLaunchKernelGGL((observe<float, true>), g, dim3(128), 0, h->stream, h->L32[prev], h->D32[prev],
+                               h->L32[cur], h->D32[cur], h->idx, h->st, p.batch, p.n_agents, p.height, p.width, P,
+                               p.obs_mask, h->scratch);
+    } else {
+        const PhysF64 P = make_f64(p, L_init);
+        if (h->f64 == F64_CUR)
+            hipLaunchKernelGGL((observe<double, false>), g, dim3(128), 0, h->stream, h->L64, h->D64, h->L32[cur],
+                               h->D32[cur], h->idx, h->st, p.batch, p.n_agents, p.height, p.width, P, p.obs_mask,
+                               h->scratch);
+        else
+            hipLaunchKernelGGL((observe<float, false>), g, dim3(128), 0, h->stream, h->L32[cur], h->D32[cur],
+                               h->L32[cur], h->D32[cur], h->idx, h->st, p.batch, p.n_agents, p.height, p.width, P,
+                               p.obs_mask, h->scratch);
+    }
+    HIPCHK(hipGetLastError());
+    return DW_OK;
+}
+
+int dw_policy_mlp(dw_handle* h, const double* params, int32_t n_params, int32_t agent_begin, int32_t agent_end,
+                  double L_init) {
+    NEED(h && params, DW_EINVAL, "null argument");
+    const dw_params& p = h->prm;
+    HIPCHK(hipSetDevice(p.device));
+    NEED(n_params == 63 * 16 + 16 * 32 + 32 * 9, DW_EINVAL, "the MLP policy has 1808 parameters (63-16-32-9), got %d", n_params);
+    NEED(agent_begin >= 0 && agent_begin <= agent_end && agent_end <= p.n_agents, DW_EINVAL, "bad agent range");
+    NEED(h->have_state && h->have_agents, DW_ESTATE, "no state / agents");
+    const size_t bn = (size_t)p.batch * p.n_agents;
+    if (bn == 0 || agent_begin == agent_end) return DW_OK;
+    int rc = observe_into_scratch(h, L_init, sizeof(double) * 1808);
+    if (rc) return rc;
+    double* d_w = h->scratch + bn * 63;
+    HIPCHK(hipMemcpyAsync(d_w, params, sizeof(double) * 1808, hipMemcpyHostToDevice, h->stream));
+    const int n = p.batch * (agent_end - agent_begin);
+    hipLaunchKernelGGL(policy_mlp, dim3((n + 63) / 64), dim3(64), 0, h->stream, h->scratch, d_w, p.batch, p.n_agents,
+                       agent_begin, agent_end, h->action);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));       // params is a caller-owned host buffer
+    return DW_OK;
+}
+
 int dw_lifespan_reset(dw_handle* h) {
     NEED(h, DW_EINVAL, "null handle");
     const dw_params& p = h->prm;

@@ -1599,6 +1599,55 @@ __global__ void policy_greedy(const float* __restrict__ cL, const float* __restr
     action[an] = 4 + best;
 }
 
+// ---------------------------------------------------------------------------------------------
+// policy_mlp — ref MLP.get_action (daisy/agents/mlp.py:97-116): 63 -> 16 -> 32 -> 9 ReLU network on
+// the flattened (7,3,3) observation, action = argmax of the logits (first maximum).  float64 like the
+// reference.  One thread per (world, agent) for agents [a0, a1) of every world; `obs` is the
+// [B][N][63] buffer written by `observe`, `W` the flat parameter vector (three matrices raveled
+// row-major in layer order, ref get_parameters :118-125).  SURVEY.md §8(f) row N3.
+// ---------------------------------------------------------------------------------------------
+__global__ void policy_mlp(const double* __restrict__ obs, const double* __restrict__ W, int B, int N, int a0, int a1,
+                           int* __restrict__ action) {
+    const int na = a1 - a0;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B * na) return;
+    const int b = t / na, n = a0 + (t - b * na);
+    const double* x = obs + ((size_t)b * N + n) * 63;
+    const double* W1 = W;                 // [63][16]
+    const double* W2 = W + 63 * 16;       // [16][32]
+    const double* W3 = W2 + 16 * 32;      // [32][9]
+    double h1[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) h1[j] = 0.0;
+    for (int i = 0; i < 63; ++i) {
+        const double xi = x[i];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) h1[j] += xi * W1[i * 16 + j];
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) h1[j] = h1[j] * (h1[j] > 0.0 ? 1.0 : 0.0);
+    double h2[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) h2[j] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+#pragma unroll
+        for (int j = 0; j < 32; ++j) h2[j] += h1[i] * W2[i * 32 + j];
+    }
+#pragma unroll
+    for (int j = 0; j < 32; ++j) h2[j] = h2[j] * (h2[j] > 0.0 ? 1.0 : 0.0);
+    int best = 0;
+    double bestv = 0.0;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        double v = 0.0;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) v += h2[i] * W3[i * 9 + j];
+        if (j == 0 || v > bestv) { best = j; bestv = v; }
+    }
+    action[(size_t)b * N + n] = best;
+}
+
 // lifespan counters (ref notebooks/greedy_longevity_abatement.ipynb cell 2:46-52)
 __global__ void lifespan_accumulate(const StatsDev* __restrict__ stats, const double* __restrict__ st,
                                     int B, int N, unsigned int thr, int* __restrict__ done_at,

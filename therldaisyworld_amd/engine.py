@@ -192,6 +192,11 @@ class Engine:
     def policy_greedy(self, argmin=False):
         check(self._lib.dw_policy_greedy(self._h, _ffi.POLICY_ARGMIN if argmin else _ffi.POLICY_ARGMAX))
 
+    def policy_mlp(self, params, agent_begin=0, agent_end=None, L_init=0.75):
+        w = np.ascontiguousarray(params, dtype=np.float64).ravel()
+        end = self.N if agent_end is None else int(agent_end)
+        check(self._lib.dw_policy_mlp(self._h, _ffi.ptr_d(w), int(w.size), int(agent_begin), end, float(L_init)))
+
     def lifespan_reset(self):
         check(self._lib.dw_lifespan_reset(self._h))
 

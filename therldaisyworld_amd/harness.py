@@ -109,3 +109,35 @@ def simulate_lifespan(env, agent, chunk=32, use_device_loop=True):
         env._invalidate()
         if executed < K:
             return done_at, agents_done_at
+
+
+def get_fitness(env, agent, adversary, max_steps=768):
+    """ref SimpleGaussianES.get_fitness (daisy/evo/sges.py:144-181): one episode in which the first half
+    of every world's agents is driven by `agent` and the second half by `adversary` (both MLP policies);
+    returns (fitness, total_steps, done_at) exactly as the reference computes them.  The policies run on
+    the device from the device-resident state (`policy_mlp`), the actions never leave the device; only the
+    (B,N) rewards come back per step for the reference's float64 mean."""
+    agent.reset()
+    obs = env.reset()
+    B, N = obs.shape[0], obs.shape[1]
+    half = N // 2
+    eng = env._engine
+    done_at = np.zeros((B, N, 1), dtype=int)
+    total_steps = 0
+    sum_reward = 0.0
+    all_done = False
+    while not all_done and env.step_count < max_steps:
+        agent.act_on_device(env, 0, half)
+        adversary.act_on_device(env, half, N)
+        eng.step_device_actions(env.L)
+        env._L_pass = env.L
+        env._invalidate()
+        reward, done = eng.reward_done()
+        reward = reward * (reward > 0)
+        all_done = (np.ones_like(done).sum() - done.sum()) == 0
+        done_at += (1 - 1 * done)
+        sum_reward += (reward[:, :half]).mean()
+        total_steps = total_steps + (1 - 1 * done)
+        env.L = env.update_L(env.L)
+    fitness = sum_reward / (B * N)
+    return fitness, total_steps, done_at.tolist()
