@@ -269,6 +269,13 @@ int dw_kernel_info(dw_handle* h, char* buf, size_t buflen);
  * step (summed over worlds). */
 int dw_last_fixup_count(dw_handle* h, uint64_t* count);
 
+/* Audit of the exact mode's error bound on the CURRENT (quantised) state at luminosity L: evaluates
+ * every cell's per-mille growth in the kernels' float32 arithmetic and in float64 and returns
+ *   out[0] max |gq_f32 - gq_f64| in quanta, out[1] max of that error divided by the cell's bound
+ *   eps (the bound holds iff < 1), out[2] cells the tie test would flag, out[3] cell-values audited.
+ * Used by the tests to show the analytic bound of DESIGN.md is never approached. */
+int dw_audit_tie_bound(dw_handle* h, double L, double out[4]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -676,3 +676,31 @@ def test_get_fitness_harness_matches_reference_rollout_g10(amd, golden):
     assert np.array_equal(total_steps, (1 - 1 * g["dones"]).sum(axis=0))
     assert np.array_equal(env2.grid, g["grid_final"])
     env.close(); env2.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# the exact mode's error bound, audited
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("over", [
+    dict(), dict(albedo_light=0.5, albedo_dark=0.5), dict(q2=0.0), dict(dt=2.0, albedo_light=0.8, albedo_dark=0.2),
+    dict(gamma=0.3, temp_optimal=290.0, g=0.004), dict(dt=0.5)])
+def test_tie_bound_is_never_approached(amd, over):
+    """|gq_f32 - gq_f64| against the per-cell bound eps of the tie test, over whole trajectories
+    (luminosity ramp 0.75 -> 1.5, 26 M cell-values per constant set): the float32 error must stay
+    below HALF the bound everywhere (the bound already carries a safety factor 2), and the flagged
+    fraction must stay small enough for the fix-up to be cheap."""
+    B, G = 8, 128
+    eng = _engine(amd, B, G, G, 0, "exact", **over)
+    eng.init_random(17)
+    L, dL = 0.75, 0.75 / 100
+    L = eng.step_n(1, L, dL, 0.75, 1.5)
+    worst_ratio, worst_err, flagged, total = 0.0, 0.0, 0, 0
+    for _ in range(100):
+        err, ratio, nf, n = eng.audit_tie_bound(L)
+        worst_ratio, worst_err = max(worst_ratio, ratio), max(worst_err, err)
+        flagged += nf
+        total += n
+        L = eng.step_n(1, L, dL, 0.75, 1.5)
+    assert worst_ratio < 0.5, (worst_ratio, worst_err)
+    assert flagged / total < 0.02, flagged / total
+    eng.close()

@@ -89,6 +89,7 @@ SIGNATURES = {
     "dw_device_planes": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), C.POINTER(_vp)]),
     "dw_kernel_info": (C.c_int, [_vp, C.c_char_p, C.c_size_t]),
     "dw_last_fixup_count": (C.c_int, [_vp, C.POINTER(_u64)]),
+    "dw_audit_tie_bound": (C.c_int, [_vp, _dbl, _pd]),
 }
 
 _libs = {}

@@ -200,7 +200,7 @@ static PhysF32 derive_f32(const dw_params& p, double L) {
     const double dabs = std::fmax(std::fabs(std::pow(std::fmax(1.0 + emax, 1e-6), 0.25) - 1.0),
                                   std::fabs(std::pow(std::fmax(1.0 + emin, 1e-6), 0.25) - 1.0));
     const double cb = p.g * p.temp_optimal * p.temp_optimal;
-    const double safety = 2.0;
+    const double safety = 1.25;   // on top of the worst-case analysis; the audit (dw_audit_tie_bound) sees <= 0.25 of eps
     const double A0 = safety * (0.25 * kmax * std::fabs(p.dt) * cb * dabs * de_abs + 4.0 * u * kmax * 0.25 + 2e-5);
     P.tie_lo = (float)(0.5 - A0);
     P.eA = (float)(safety * 9.0 * u);
@@ -1325,6 +1325,29 @@ int dw_kernel_info(dw_handle* h, char* buf, size_t buflen) {
         snprintf(buf, buflen, "step_generic<%s> one thread per cell, grid=(%d,%d) x 256 threads", prec,
                  (p.height * p.width + 255) / 256, p.batch);
     }
+    return DW_OK;
+}
+
+int dw_audit_tie_bound(dw_handle* h, double L, double out[4]) {
+    NEED(h && out, DW_EINVAL, "null argument");
+    const dw_params& p = h->prm;
+    HIPCHK(hipSetDevice(p.device));
+    NEED(h->have_state && h->cur_quantised, DW_ESTATE, "the audit needs a quantised current state");
+    int rc = ensure_scratch(h, 4 * sizeof(unsigned long long));
+    if (rc) return rc;
+    unsigned long long* d = reinterpret_cast<unsigned long long*>(h->scratch);
+    HIPCHK(hipMemsetAsync(d, 0, 4 * sizeof(unsigned long long), h->stream));
+    const dim3 g((unsigned)((p.height * p.width + 255) / 256), (unsigned)p.batch);
+    hipLaunchKernelGGL(tie_audit, g, dim3(256), 0, h->stream, h->L32[h->cur], h->D32[h->cur], p.height, p.width,
+                       derive_f32(p, L), make_f64(p, L), d);
+    HIPCHK(hipGetLastError());
+    unsigned long long r[4];
+    HIPCHK(hipMemcpyAsync(r, d, sizeof(r), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    std::memcpy(&out[0], &r[0], sizeof(double));
+    std::memcpy(&out[1], &r[1], sizeof(double));
+    out[2] = (double)r[2];
+    out[3] = (double)r[3];
     return DW_OK;
 }
 

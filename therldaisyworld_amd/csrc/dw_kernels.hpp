@@ -1648,6 +1648,59 @@ __global__ void policy_mlp(const double* __restrict__ obs, const double* __restr
     action[(size_t)b * N + n] = best;
 }
 
+// ---------------------------------------------------------------------------------------------
+// tie_audit — evidence for the exact mode's error bound.  For every cell of a quantised state:
+// float32 per-mille growth gq32 (the hot kernels' arithmetic, split coefficient chains) against the
+// float64 growth of cell_f64, and the per-cell bound eps the tie test would use.  Reduces
+//   out[0] = max |gq32 - gq64| (quanta)      out[1] = max (|gq32 - gq64| / eps)   (< 1 <=> bound holds)
+//   out[2] = number of cells the tie test flags   out[3] = number of cells audited
+// (both species count).  Non-negative doubles order like their bit patterns: atomicMax on u64.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tie_audit(const float* __restrict__ L, const float* __restrict__ D, int H, int W,
+                                                 PhysF32 P, PhysF64 P64, unsigned long long* __restrict__ out) {
+    const int b = blockIdx.y;
+    const int cell = blockIdx.x * 256 + threadIdx.x;
+    if (cell >= H * W) return;
+    const size_t woff = (size_t)b * H * W;
+    const float* pl = L + woff;
+    const float* pd = D + woff;
+    const int r = cell / W, c = cell - r * W;
+    const int ru = r == 0 ? H - 1 : r - 1, rd = r == H - 1 ? 0 : r + 1;
+    const int cl = c == 0 ? W - 1 : c - 1, cr = c == W - 1 ? 0 : c + 1;
+#define DW_AT(p, rr, cc) (p)[(size_t)(rr) * W + (cc)]
+    const float li = DW_AT(pl, r, c), di = DW_AT(pd, r, c);
+    const float El = (DW_AT(pl, ru, c) + DW_AT(pl, rd, c)) + (DW_AT(pl, r, cl) + DW_AT(pl, r, cr));
+    const float Cl = (DW_AT(pl, ru, cl) + DW_AT(pl, rd, cl)) + (DW_AT(pl, ru, cr) + DW_AT(pl, rd, cr));
+    const float Ed = (DW_AT(pd, ru, c) + DW_AT(pd, rd, c)) + (DW_AT(pd, r, cl) + DW_AT(pd, r, cr));
+    const float Cd = (DW_AT(pd, ru, cl) + DW_AT(pd, rd, cl)) + (DW_AT(pd, ru, cr) + DW_AT(pd, rd, cr));
+#undef DW_AT
+    const GrowthF32 g = growth_f32<true>(P, li, di, El, Cl, Ed, Cd);
+    double l9[9], d9[9];
+    gather9(pl, H, W, r, c, l9);
+    gather9(pd, H, W, r, c, d9);
+    const CellF64 o = cell_f64(P64, l9, d9);
+    const double g64[2] = {P64.dt * o.gl * 1000.0, P64.dt * o.gd * 1000.0};
+    const float g32[2] = {g.gql, g.gqd};
+    const float dK[2] = {g.dKl, g.dKd};
+    const float om[2] = {g.oml, g.omd};
+    double max_err = 0.0, max_ratio = 0.0;
+    unsigned long long flagged = 0;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const float thr = fmaf(-fabsf(dK[k]), fmaf(P.eK1, om[k], P.eK0), fmaf(-P.eA, fabsf(g32[k]), P.tie_lo));
+        const double eps = 0.5 - (double)thr;
+        const double err = fabs((double)g32[k] - g64[k]);
+        max_err = fmax(max_err, err);
+        max_ratio = fmax(max_ratio, err / eps);
+        const float rr = __builtin_rintf(g32[k]);
+        flagged += fabsf(g32[k] - rr) > thr ? 1ull : 0ull;
+    }
+    atomicMax(&out[0], (unsigned long long)__double_as_longlong(max_err));
+    atomicMax(&out[1], (unsigned long long)__double_as_longlong(max_ratio));
+    if (flagged) atomicAdd(&out[2], flagged);
+    atomicAdd(&out[3], 2ull);
+}
+
 // lifespan counters (ref notebooks/greedy_longevity_abatement.ipynb cell 2:46-52)
 __global__ void lifespan_accumulate(const StatsDev* __restrict__ stats, const double* __restrict__ st,
                                     int B, int N, unsigned int thr, int* __restrict__ done_at,

@@ -254,6 +254,12 @@ class Engine:
         check(self._lib.dw_kernel_info(self._h, buf, 512))
         return buf.value.decode()
 
+    def audit_tie_bound(self, L):
+        """(max |gq32-gq64| in quanta, max error/bound, flagged cell-values, audited cell-values)."""
+        out = np.zeros(4)
+        check(self._lib.dw_audit_tie_bound(self._h, float(L), _ffi.ptr_d(out)))
+        return float(out[0]), float(out[1]), int(out[2]), int(out[3])
+
     def last_fixup_count(self) -> int:
         v = C.c_uint64(0)
         check(self._lib.dw_last_fixup_count(self._h, C.byref(v)))
