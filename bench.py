@@ -63,6 +63,8 @@ def parse():
                          "north star states; the other of exact/fast is measured too and reported under 'modes')")
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--no-modes", action="store_true", help="skip the extra run in the other arithmetic mode")
     return ap.parse_args()
 
@@ -134,8 +136,10 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    if os.environ.get("DW_BENCH_ALL_RANKS_ON_DEVICE0"):     # rehearsal of the N > 1 path on a 1-GPU box
+        local_rank = 0
     torch.cuda.set_device(local_rank)
-    dist = ensemble.init_process_group("nccl") if world > 1 else None
+    dist = ensemble.init_process_group(args.backend) if world > 1 else None
 
     import therldaisyworld_amd as amd
     from therldaisyworld_amd import _ffi
