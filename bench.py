@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — cell-updates/s of the fused RLDaisyWorld step on MI355X, with roofline and CPU baseline.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c5|c1|target] [--precision exact|fast]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4|c5|c1|target] [--precision fast|exact]
 
 A "step" is one pass of the hot path (ref RLDaisyWorld.step, daisy_world_rl.py:475-497) over the
 whole batch of synthetic worlds: update_agents (if the workload has agents) + the fused
@@ -48,6 +48,8 @@ WORKLOADS = {
     "c3": (256, 1024, 1, "BASELINE configs[2]: 256 worlds, 1024x1024, 1 greedy agent per world"),
     "c5": (8, 8192, 16, "BASELINE configs[4] per-GPU shard: 8 worlds, 8192x8192, 16 mixed-policy agents"),
     "target": (256, 4096, 0, "north-star grid: 4096x4096 worlds, no agent (worlds sized to fit beside other tenants)"),
+    "c4": (1000, 8, 4, "BASELINE configs[3] per-GPU shard at the README's grid: 1000 worlds, 8x8, 4 greedy agents, "
+                       "device-resident episode loop (dw_run_episode)"),
 }
 
 
@@ -165,6 +167,21 @@ def main():
         def run(nsteps, L):
             if N == 0:
                 return eng.step_n(nsteps, L, dL, min_L, max_L)
+            if args.workload == "c4":                       # small worlds: whole chunks of steps in one launch
+                if L == min_L:                              # first step from the un-quantised state
+                    eng.policy_greedy(argmin=False)
+                    eng.step_device_actions(L)
+                    L = min(max(L + dL, min_L), max_L)
+                    nsteps -= 1
+                while nsteps > 0:
+                    k = min(nsteps, 64)
+                    Ls = []
+                    for _ in range(k):
+                        Ls.append(L)
+                        L = min(max(L + dL, min_L), max_L)
+                    eng.run_episode(Ls, _ffi.POLICY_ARGMAX)
+                    nsteps -= k
+                return L
             for _ in range(nsteps):
                 if args.workload == "c5":
                     eng.policy_greedy(argmin=False)
