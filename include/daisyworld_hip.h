@@ -185,7 +185,11 @@ int dw_download_actions(dw_handle* h, int32_t* action /* [B][N] */);
 int dw_step_n(dw_handle* h, int32_t nsteps, double* L_io, double dL, double min_L, double max_L,
               int use_device_actions);
 
-/* update_agents alone (ref :181-244) and forward alone on caller data (ref :434-461): the latter
+/* update_agents alone (ref :181-244) and forward alone on caller data (ref :434-461).  With
+ * collision_mode = 1 dw_update_agents stops before the final clip: the reference's collision pass
+ * (:220-242) draws from the caller's legacy RNG once per multiply-occupied cell, so the caller applies
+ * it to the downloaded agent states, clips and uploads them (the Python drop-in does), then steps
+ * without actions; dw_step / dw_run_episode with actions refuse collision_mode = 1.  dw_forward_f64
  * is stateless w.r.t. the cover planes: host covers [B][H][W] float64 in, 7-channel grid out
  * (agent states of the handle are written into channel 4 as the reference does); the optional
  * cache outputs are those of dw_download_caches for that input. */

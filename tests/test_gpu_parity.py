@@ -704,3 +704,51 @@ def test_tie_bound_is_never_approached(amd, over):
     assert worst_ratio < 0.5, (worst_ratio, worst_err)
     assert flagged / total < 0.02, flagged / total
     eng.close()
+
+
+def test_dropin_collision_mode_g8(amd, golden):
+    """collision_mode=1 with its as-implemented semantics (winner gains, losers unchanged, one RNG draw
+    per multiply-occupied cell): agent states identical to the reference fixture."""
+    g = golden("G8_collisions")
+    np.random.seed(31)
+    env = amd.RLDaisyWorld(grid_dimension=5, n_agents=4, collision_mode=1)
+    env.batch_size = 3
+    env.reset()
+    env.agent_indices[0] = np.array([[2, 2], [2, 2], [1, 1], [4, 4]])
+    env.agent_indices[1] = np.array([[0, 0], [0, 0], [0, 0], [3, 3]])
+    env.agent_states[0, :, 0] = np.array([0.6, 0.4, 0.9, 0.2])
+    env.agent_states[1, :, 0] = np.array([0.5, 0.7, 0.3, 0.8])
+    assert np.array_equal(env.grid[:, 1], g["light0"]) and np.array_equal(env.agent_indices, g["agent_indices0"])
+    np.random.seed(int(g["jitter_seed"]))
+    for t in range(6):
+        env.step(np.full((3, 4, 1), 8))
+        assert np.array_equal(env.agent_indices, g["agent_indices"][t])
+        assert np.array_equal(env.agent_states, g["agent_states"][t]), t
+    assert np.array_equal(env.grid, g["grid_final"])
+    env.close()
+
+
+@pytest.mark.parametrize("mode", ["moore", "circular", "von_neumann"])
+def test_dropin_neighbourhood_modes_vs_oracle(amd, mode):
+    """Observation masks of the three reference neighbourhood modes at kr=1 (ref nn/functional.py:51-103;
+    circular == von Neumann at radius 1): observations, rewards and grids equal the oracle's."""
+    np.random.seed(9)
+    env = amd.RLDaisyWorld(grid_dimension=10, n_agents=3, neighborhood_mode=mode)
+    env.batch_size = 4
+    obs = env.reset()
+    np.random.seed(9)
+    ref = O.OracleDaisyWorld.like_reference_ctor(grid_dimension=10, n_agents=3, neighborhood_mode=mode)
+    ref.P.batch_size = 4
+    robs = ref.reset()
+    np.testing.assert_allclose(obs, robs, rtol=1e-12, atol=0)
+    assert (obs[:, :, :, 0, 0] != 0).any() == (mode == "moore")
+    rng = np.random.RandomState(2)
+    for _ in range(8):
+        a = rng.randint(9, size=(4, 3, 1))
+        obs, reward, done, _ = env.step(a)
+        robs, rreward, rdone, _ = ref.step(a)
+        assert np.array_equal(obs, robs) and np.array_equal(reward, rreward) and np.array_equal(done, rdone)
+    assert np.array_equal(env.grid, ref.grid)
+    with pytest.raises(ValueError):
+        amd.RLDaisyWorld(grid_dimension=10, kr=2)        # the reference itself cannot observe with kr != 1 (:258)
+    env.close()

@@ -445,17 +445,19 @@ static int launch_forward_fused2(dw_handle* h, double L1, double L2) {
     return DW_OK;
 }
 
-static int launch_agents(dw_handle* h, const int* d_action, int act_b, int act_n) {
+static int launch_agents(dw_handle* h, const int* d_action, int act_b, int act_n, bool standalone = false) {
     const dw_params& p = h->prm;
     if (p.n_agents == 0) return DW_OK;
     NEED(h->have_state, DW_ESTATE, "no state uploaded");
     NEED(h->have_agents, DW_ESTATE, "no agents uploaded (call dw_upload_agents or dw_init_random)");
-    NEED(p.collision_mode == 0, DW_EINVAL, "collision_mode=1 is not implemented on the device");
+    NEED(p.collision_mode == 0 || standalone, DW_EINVAL,
+         "collision_mode=1: call dw_update_agents, apply the collision pass (it consumes the caller's RNG) to the "
+         "downloaded agent states, upload them, then dw_step without actions");
     const int blocks = (p.batch + 63) / 64;
     hipLaunchKernelGGL(agents_update, dim3(blocks), dim3(64), 0, h->stream, h->L32[h->cur],
                        h->D32[h->cur], h->f64 == F64_CUR ? h->L64 : nullptr,
                        h->f64 == F64_CUR ? h->D64 : nullptr, h->idx, h->st, d_action, act_b, act_n,
-                       p.batch, p.n_agents, p.height, p.width, p.agent_gamma);
+                       p.batch, p.n_agents, p.height, p.width, p.agent_gamma, p.collision_mode == 0 ? 1 : 0);
     HIPCHK(hipGetLastError());
     return DW_OK;
 }
@@ -830,7 +832,7 @@ int dw_update_agents(dw_handle* h, const int32_t* action, int32_t action_b, int3
     HIPCHK(hipSetDevice(h->prm.device));
     int rc = stage_host_actions(h, action, action_b, action_n);
     if (rc) return rc;
-    return launch_agents(h, h->action_tmp, action_b, action_n);
+    return launch_agents(h, h->action_tmp, action_b, action_n, true);
 }
 
 int dw_step(dw_handle* h, const int32_t* action, int32_t action_b, int32_t action_n, double L) {

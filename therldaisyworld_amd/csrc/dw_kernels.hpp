@@ -1394,7 +1394,7 @@ __global__ void agents_update(float* __restrict__ L32, float* __restrict__ D32,
                               double* __restrict__ f64L, double* __restrict__ f64D,
                               int* __restrict__ idx, double* __restrict__ st,
                               const int* __restrict__ action, int act_b, int act_n, int B, int N,
-                              int H, int W, double agent_gamma) {
+                              int H, int W, double agent_gamma, int do_clip) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     const size_t woff = (size_t)b * H * W;
@@ -1425,10 +1425,11 @@ __global__ void agents_update(float* __restrict__ L32, float* __restrict__ D32,
             }
         }
     }
-    for (int n = 0; n < N; ++n) {                                                // ref :244
-        const double s = st[(size_t)b * N + n];
-        st[(size_t)b * N + n] = s < 0.0 ? 0.0 : (s > 1.0 ? 1.0 : s);
-    }
+    if (do_clip)     // collision_mode 1: the collision pass (host, RNG-coupled) runs before the clip (ref :220-244)
+        for (int n = 0; n < N; ++n) {                                            // ref :244
+            const double s = st[(size_t)b * N + n];
+            st[(size_t)b * N + n] = s < 0.0 ? 0.0 : (s > 1.0 ? 1.0 : s);
+        }
 }
 
 // reward / done (ref step :486-492, N > 0):  reward = state * (state > 0); done = reward < 0.1

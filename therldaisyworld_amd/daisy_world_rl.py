@@ -338,10 +338,34 @@ class RLDaisyWorld:
         return eng.get_obs(self._L_pass)
 
     def update_agents(self, action):
-        """ref :181-244."""
+        """ref :181-244.  Movement and grazing run on the device; with collision_mode == 1 the
+        collision pass (:220-242) follows on the host because it consumes the legacy RNG stream."""
         eng = self._ensure_engine()
         self._sync_to_device()
         eng.update_agents(action)
+        self._invalidate()
+        if self.collision_mode == 1:
+            self._collision_pass()
+
+    def _collision_pass(self):
+        """ref :220-244 as implemented: per world, per cell in row-major order, if more than one agent
+        sits on the cell, the resident with the largest (state + 0.01*U) gains food_chain_penalty times
+        the summed states of the other residents; the losers keep their state (the reference zeroes a
+        copy); one np.random.rand(1,N,1) draw per multiply-occupied cell; then clip to [0,1]."""
+        idx, st = self._engine.download_agents()
+        st = st[..., None].copy()                              # (B,N,1) float64, before the clip
+        for bb in range(idx.shape[0]):
+            cells = idx[bb, :, 0].astype(np.int64) * self.dim + idx[bb, :, 1]
+            uniq, counts = np.unique(cells, return_counts=True)
+            for cell in uniq[counts > 1]:                      # np.unique sorts: row-major scan order
+                residents = (cells == cell)[None, :, None]
+                temp_values = 1.0 * st[bb:bb + 1] + 0.01 * np.random.rand(*st[bb:bb + 1].shape)
+                winner_value = np.max(temp_values[residents])
+                winner_index = temp_values == winner_value
+                eat = st[bb:bb + 1][residents][temp_values[residents] != winner_value].sum()
+                st[bb:bb + 1][winner_index] += self.food_chain_penalty * eat
+        st = np.clip(st, 0., 1.)
+        self._engine.upload_agents(idx, st[..., 0])
         self._invalidate()
 
     def forward(self, grid):
@@ -375,6 +399,9 @@ class RLDaisyWorld:
         self._sync_to_device()
         if action is None and self.n_agents:
             action = np.zeros((self.batch_size, self.n_agents, 1))
+        if self.collision_mode == 1 and action is not None:
+            self.update_agents(action)                        # device move/graze + host collision pass
+            action = None
         eng.step(self.L, action)
         self._L_pass = self.L
         self._invalidate()
