@@ -224,6 +224,13 @@ int dw_policy_greedy(dw_handle* h, int mode);
 int dw_policy_mlp(dw_handle* h, const double* params, int32_t n_params, int32_t agent_begin, int32_t agent_end,
                   double L_init);
 
+/* The same for a whole population at once: params is [n_members][1808] and world_member[B] names the
+ * parameter set each world's agents use, so that an evolution strategy evaluates all its members as ONE
+ * batched ensemble instead of one episode per member (the reference farms members out to MPI workers,
+ * daisy/evo/sges.py:314-349). */
+int dw_policy_mlp_population(dw_handle* h, const double* params, int32_t n_members, const int32_t* world_member,
+                             int32_t agent_begin, int32_t agent_end, double L_init);
+
 /* Device-resident lifespan harness (ref notebooks/greedy_longevity_abatement.ipynb cell 2:28-57):
  * accumulate done_at[b] += (max_k > threshold_k) and agents_done_at[b][n] += !(done) after each
  * step, on the device.  dw_lifespan_reset zeroes them. */

@@ -752,3 +752,43 @@ def test_dropin_neighbourhood_modes_vs_oracle(amd, mode):
     with pytest.raises(ValueError):
         amd.RLDaisyWorld(grid_dimension=10, kr=2)        # the reference itself cannot observe with kr != 1 (:258)
     env.close()
+
+
+def test_population_fitness_as_one_ensemble(amd):
+    """A population of MLP policies evaluated as one batched ensemble (dw_policy_mlp_population): each
+    member's fitness / done_at equal what the single-member get_fitness path computes on the same worlds."""
+    from therldaisyworld_amd.harness import get_fitness_population
+    np.random.seed(77)
+    pop = [amd.MLP() for _ in range(3)]
+    adversary_of = [1, 2, 0]
+    wpm, N, G = 5, 4, 8
+    np.random.seed(123)
+    env = amd.RLDaisyWorld(grid_dimension=G, n_agents=N)
+    res = get_fitness_population(env, pop, adversary_of, worlds_per_member=wpm, max_steps=30)
+    # reference arithmetic per member on ITS block of worlds: oracle environment fed the same initial state
+    np.random.seed(123)
+    ref_env = O.OracleDaisyWorld.like_reference_ctor(grid_dimension=G, n_agents=N)
+    ref_env.P.batch_size = 3 * wpm
+    obs = ref_env.reset()
+    nets = [O.OracleMLP(m.get_parameters()) for m in pop]
+    half = N // 2
+    sum_reward = np.zeros(3)
+    done_at = np.zeros((3 * wpm, N, 1), dtype=int)
+    running = np.ones(3, dtype=bool)
+    while running.any() and ref_env.step_count < 30:
+        acts = []
+        for m in range(3):
+            o = obs[m * wpm:(m + 1) * wpm]
+            acts.append(np.append(nets[m].get_action(o[:, :half]), nets[adversary_of[m]].get_action(o[:, half:]), axis=1))
+        obs, reward, done, _ = ref_env.step(np.concatenate(acts, axis=0))
+        live = np.repeat(running, wpm)[:, None, None]
+        done_at += live * (1 - 1 * done)
+        for m in range(3):
+            if running[m]:
+                sum_reward[m] += reward[m * wpm:(m + 1) * wpm, :half].mean()
+                running[m] = not done[m * wpm:(m + 1) * wpm].all()
+    for m in range(3):
+        assert res[m][0] == sum_reward[m] / (wpm * N)
+        assert np.array_equal(np.array(res[m][2]), done_at[m * wpm:(m + 1) * wpm])
+    assert np.array_equal(env.grid, ref_env.grid)
+    env.close()

@@ -78,6 +78,7 @@ SIGNATURES = {
     "dw_reduce": (C.c_int, [_vp, C.POINTER(DwWorldStats)]),
     "dw_policy_greedy": (C.c_int, [_vp, C.c_int]),
     "dw_policy_mlp": (C.c_int, [_vp, _pd, _i32, _i32, _i32, _dbl]),
+    "dw_policy_mlp_population": (C.c_int, [_vp, _pd, _i32, _pi, _i32, _i32, _dbl]),
     "dw_lifespan_reset": (C.c_int, [_vp]),
     "dw_lifespan_accumulate": (C.c_int, [_vp, _u32]),
     "dw_lifespan_download": (C.c_int, [_vp, _pi, _pi, _pi]),

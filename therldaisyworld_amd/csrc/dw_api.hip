@@ -1111,26 +1111,47 @@ static int observe_into_scratch(dw_handle* h, double L_init, size_t extra_bytes)
     return DW_OK;
 }
 
-int dw_policy_mlp(dw_handle* h, const double* params, int32_t n_params, int32_t agent_begin, int32_t agent_end,
-                  double L_init) {
-    NEED(h && params, DW_EINVAL, "null argument");
+static int policy_mlp_impl(dw_handle* h, const double* params, int32_t n_members, const int32_t* world_member,
+                           int32_t agent_begin, int32_t agent_end, double L_init) {
     const dw_params& p = h->prm;
-    HIPCHK(hipSetDevice(p.device));
-    NEED(n_params == 63 * 16 + 16 * 32 + 32 * 9, DW_EINVAL, "the MLP policy has 1808 parameters (63-16-32-9), got %d", n_params);
     NEED(agent_begin >= 0 && agent_begin <= agent_end && agent_end <= p.n_agents, DW_EINVAL, "bad agent range");
     NEED(h->have_state && h->have_agents, DW_ESTATE, "no state / agents");
     const size_t bn = (size_t)p.batch * p.n_agents;
     if (bn == 0 || agent_begin == agent_end) return DW_OK;
-    int rc = observe_into_scratch(h, L_init, sizeof(double) * 1808);
+    if (world_member)
+        for (int b = 0; b < p.batch; ++b)
+            NEED(world_member[b] >= 0 && world_member[b] < n_members, DW_EINVAL, "world %d: member %d out of range", b,
+                 world_member[b]);
+    const size_t wbytes = sizeof(double) * 1808 * (size_t)n_members;
+    const size_t mbytes = world_member ? sizeof(int) * (size_t)p.batch : 0;
+    int rc = observe_into_scratch(h, L_init, wbytes + mbytes + 16);
     if (rc) return rc;
     double* d_w = h->scratch + bn * 63;
-    HIPCHK(hipMemcpyAsync(d_w, params, sizeof(double) * 1808, hipMemcpyHostToDevice, h->stream));
+    int* d_m = world_member ? reinterpret_cast<int*>(d_w + 1808 * (size_t)n_members) : nullptr;
+    HIPCHK(hipMemcpyAsync(d_w, params, wbytes, hipMemcpyHostToDevice, h->stream));
+    if (world_member) HIPCHK(hipMemcpyAsync(d_m, world_member, mbytes, hipMemcpyHostToDevice, h->stream));
     const int n = p.batch * (agent_end - agent_begin);
-    hipLaunchKernelGGL(policy_mlp, dim3((n + 63) / 64), dim3(64), 0, h->stream, h->scratch, d_w, p.batch, p.n_agents,
-                       agent_begin, agent_end, h->action);
+    hipLaunchKernelGGL(policy_mlp, dim3((n + 63) / 64), dim3(64), 0, h->stream, h->scratch, d_w, d_m, p.batch,
+                       p.n_agents, agent_begin, agent_end, h->action);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(h->stream));       // params is a caller-owned host buffer
+    HIPCHK(hipStreamSynchronize(h->stream));       // params / world_member are caller-owned host buffers
     return DW_OK;
+}
+
+int dw_policy_mlp(dw_handle* h, const double* params, int32_t n_params, int32_t agent_begin, int32_t agent_end,
+                  double L_init) {
+    NEED(h && params, DW_EINVAL, "null argument");
+    HIPCHK(hipSetDevice(h->prm.device));
+    NEED(n_params == 63 * 16 + 16 * 32 + 32 * 9, DW_EINVAL, "the MLP policy has 1808 parameters (63-16-32-9), got %d", n_params);
+    return policy_mlp_impl(h, params, 1, nullptr, agent_begin, agent_end, L_init);
+}
+
+int dw_policy_mlp_population(dw_handle* h, const double* params, int32_t n_members, const int32_t* world_member,
+                             int32_t agent_begin, int32_t agent_end, double L_init) {
+    NEED(h && params && world_member, DW_EINVAL, "null argument");
+    HIPCHK(hipSetDevice(h->prm.device));
+    NEED(n_members >= 1, DW_EINVAL, "n_members < 1");
+    return policy_mlp_impl(h, params, n_members, world_member, agent_begin, agent_end, L_init);
 }
 
 int dw_lifespan_reset(dw_handle* h) {

@@ -1607,13 +1607,16 @@ __global__ void policy_greedy(const float* __restrict__ cL, const float* __restr
 // [B][N][63] buffer written by `observe`, `W` the flat parameter vector (three matrices raveled
 // row-major in layer order, ref get_parameters :118-125).  SURVEY.md §8(f) row N3.
 // ---------------------------------------------------------------------------------------------
-__global__ void policy_mlp(const double* __restrict__ obs, const double* __restrict__ W, int B, int N, int a0, int a1,
-                           int* __restrict__ action) {
+// `member` (optional): parameter set of each world — a whole ES population evaluated as one ensemble
+// (world b uses W + member[b] * 1808); nullptr = one set for all worlds.
+__global__ void policy_mlp(const double* __restrict__ obs, const double* __restrict__ W, const int* __restrict__ member,
+                           int B, int N, int a0, int a1, int* __restrict__ action) {
     const int na = a1 - a0;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= B * na) return;
     const int b = t / na, n = a0 + (t - b * na);
     const double* x = obs + ((size_t)b * N + n) * 63;
+    if (member) W += (size_t)member[b] * 1808;
     const double* W1 = W;                 // [63][16]
     const double* W2 = W + 63 * 16;       // [16][32]
     const double* W3 = W2 + 16 * 32;      // [32][9]

@@ -197,6 +197,18 @@ class Engine:
         end = self.N if agent_end is None else int(agent_end)
         check(self._lib.dw_policy_mlp(self._h, _ffi.ptr_d(w), int(w.size), int(agent_begin), end, float(L_init)))
 
+    def policy_mlp_population(self, params, world_member, agent_begin=0, agent_end=None, L_init=0.75):
+        """params (P,1808); world_member (B,) int: which parameter set each world's agents use."""
+        w = np.ascontiguousarray(params, dtype=np.float64)
+        if w.ndim != 2 or w.shape[1] != 1808:
+            raise ValueError("params must have shape (n_members, 1808)")
+        m = np.ascontiguousarray(world_member, dtype=np.int32)
+        if m.shape != (self.B,):
+            raise ValueError(f"world_member must have shape {(self.B,)}")
+        end = self.N if agent_end is None else int(agent_end)
+        check(self._lib.dw_policy_mlp_population(self._h, _ffi.ptr_d(w), int(w.shape[0]), _ffi.ptr_i(m),
+                                                 int(agent_begin), end, float(L_init)))
+
     def lifespan_reset(self):
         check(self._lib.dw_lifespan_reset(self._h))
 

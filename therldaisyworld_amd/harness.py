@@ -141,3 +141,52 @@ def get_fitness(env, agent, adversary, max_steps=768):
         env.L = env.update_L(env.L)
     fitness = sum_reward / (B * N)
     return fitness, total_steps, done_at.tolist()
+
+
+def get_fitness_population(env, population, adversary_of=None, worlds_per_member=32, max_steps=768):
+    """All members of an evolution-strategy population evaluated as ONE batched ensemble (SURVEY.md §8f
+    N3; the reference runs `get_fitness` once per member and farms members out to MPI workers,
+    daisy/evo/sges.py:314-349).  `population` is a list of MLP policies (or a (P,1808) array);
+    member m owns worlds [m*worlds_per_member, (m+1)*worlds_per_member); in each of its worlds the
+    first half of the agents is driven by member m and the second half by member adversary_of[m]
+    (default: itself).  Returns per-member (fitness, total_steps, done_at) computed exactly as
+    `get_fitness` computes them for that member's block of worlds.
+
+    Each member's episode ends when all ITS agents are done (or at max_steps), as in the reference; the
+    ensemble keeps stepping until every member has finished, and a finished member's statistics are
+    frozen at its own stopping step.  (With the legacy-RNG reset the worlds differ from P separate
+    `reset()` calls of the reference; the per-member arithmetic is the same.)"""
+    params = np.stack([m.get_parameters() if hasattr(m, "get_parameters") else np.asarray(m) for m in population])
+    P = params.shape[0]
+    adversary_of = np.arange(P) if adversary_of is None else np.asarray(adversary_of, dtype=int)
+    env.batch_size = P * worlds_per_member
+    obs = env.reset()
+    B, N = obs.shape[0], obs.shape[1]
+    half = N // 2
+    eng = env._engine
+    member = np.repeat(np.arange(P), worlds_per_member).astype(np.int32)
+    adv_member = adversary_of[member].astype(np.int32)
+    done_at = np.zeros((B, N, 1), dtype=int)
+    total_steps = np.zeros((B, N, 1), dtype=int)
+    sum_reward = np.zeros(P)
+    running = np.ones(P, dtype=bool)
+    while running.any() and env.step_count < max_steps:
+        env._sync_to_device()
+        eng.policy_mlp_population(params, member, 0, half, env._L_pass)
+        eng.policy_mlp_population(params, adv_member, half, N, env._L_pass)
+        eng.step_device_actions(env.L)
+        env._L_pass = env.L
+        env._invalidate()
+        reward, done = eng.reward_done()
+        reward = reward * (reward > 0)
+        live = np.repeat(running, worlds_per_member)[:, None, None]
+        done_at += live * (1 - 1 * done)
+        total_steps += live * (1 - 1 * done)
+        r = reward.reshape(P, worlds_per_member, N, 1)
+        d = done.reshape(P, worlds_per_member, N, 1)
+        sum_reward += running * r[:, :, :half].mean(axis=(1, 2, 3))
+        running &= ~d.reshape(P, -1).all(axis=1)
+        env.L = env.update_L(env.L)
+    fitness = sum_reward / (worlds_per_member * N)
+    return [(fitness[m], total_steps[m * worlds_per_member:(m + 1) * worlds_per_member],
+             done_at[m * worlds_per_member:(m + 1) * worlds_per_member].tolist()) for m in range(P)]
