@@ -85,6 +85,9 @@ SHAPES = [
     (1, 70, 320),     # tiled TCQ=64, partial column tile + partial row tile
     (1, 33, 516),     # W % 4 == 0 but not a multiple of the tile width; H = TR + 1
     (1, 40, 258),     # W % 4 != 0 -> generic
+    (2, 3, 256),      # streaming kernel, strip shorter than one row block
+    (1, 5, 512),      # streaming kernel, dpp-old halo, odd tiny height
+    (1, 65, 260),     # streaming kernel, general halo: second strip has a single active lane; H = SR + 1
 ]
 
 
@@ -539,7 +542,8 @@ def test_c1_trajectory_via_episode_kernel_g2(amd, golden):
 # ---------------------------------------------------------------------------------------------
 # temporal fusion (two steps per HBM round trip, float32-only mode)
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("B,H,W", [(3, 256, 256), (2, 100, 256), (1, 70, 320), (1, 130, 516), (2, 64, 1024)])
+@pytest.mark.parametrize("B,H,W", [(3, 256, 256), (2, 100, 256), (1, 70, 320), (1, 130, 516), (2, 64, 1024),
+                                   (2, 3, 256), (1, 5, 500), (1, 65, 260)])
 @pytest.mark.parametrize("nsteps", [3, 8, 13])
 @pytest.mark.parametrize("precision", ["fast", "exact"])
 def test_fused_step_pairs_equal_single_steps(amd, monkeypatch, B, H, W, nsteps, precision):
