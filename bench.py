@@ -184,14 +184,19 @@ def main():
                 return L
             for _ in range(nsteps):
                 if args.workload == "c5":
-                    eng.policy_greedy(argmin=False)
-                    a = eng.download_actions()
-                    eng.policy_greedy(argmin=True)
-                    a[:, 4:8] = eng.download_actions()[:, 4:8]
+                    # agents 0-3 greedy, 4-7 antigreedy, 8-11 random, 12-15 half-random (one coin per step
+                    # for the batch, as Greedy does): random actions are host-drawn and uploaded, the
+                    # deterministic ones are filled in on the device; nothing is downloaded
+                    a = np.zeros((B, 16), dtype=np.int32)
                     a[:, 8:12] = rng.randint(9, size=(B, 4))
-                    if not (rng.rand() > 0.5):
+                    mode = [_ffi.POLICY_ARGMAX] * 4 + [_ffi.POLICY_ARGMIN] * 4 + [_ffi.POLICY_TABLE] * 4
+                    if rng.rand() > 0.5:
+                        mode += [_ffi.POLICY_ARGMAX] * 4
+                    else:
                         a[:, 12:16] = rng.randint(9, size=(B, 4))
+                        mode += [_ffi.POLICY_TABLE] * 4
                     eng.upload_actions(a)
+                    eng.policy_per_agent(mode)
                 else:
                     eng.policy_greedy(argmin=False)
                 eng.step_device_actions(L)

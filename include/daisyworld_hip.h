@@ -215,6 +215,11 @@ int dw_reduce(dw_handle* h, dw_world_stats* per_world /* [B] */);
  * dw_upload_actions. */
 int dw_policy_greedy(dw_handle* h, int mode);
 
+/* Mixed-policy ensembles (BASELINE configs[4]: policy chosen by agent index): agent_mode[N] per agent
+ * index DW_POLICY_ARGMAX, DW_POLICY_ARGMIN, or DW_POLICY_TABLE = keep the action already in the device
+ * action buffer (host-drawn random actions put there with dw_upload_actions). */
+int dw_policy_per_agent(dw_handle* h, const int32_t* agent_mode);
+
 /* Learned policy on the device (ref MLP.get_action, daisy/agents/mlp.py:97-116):
  * the 63 -> 16 -> 32 -> 9 ReLU network evaluated in float64 on the current observations of agents
  * [agent_begin, agent_end) of every world; argmax of the logits goes to the device action buffer.

@@ -796,3 +796,24 @@ def test_population_fitness_as_one_ensemble(amd):
         assert np.array_equal(np.array(res[m][2]), done_at[m * wpm:(m + 1) * wpm])
     assert np.array_equal(env.grid, ref_env.grid)
     env.close()
+
+
+def test_policy_per_agent_modes(amd):
+    from therldaisyworld_amd import _ffi
+    np.random.seed(3)
+    env = amd.RLDaisyWorld(grid_dimension=8, n_agents=6)
+    env.batch_size = 16
+    env.reset()
+    for _ in range(4):
+        obs, *_ = env.step(np.random.randint(9, size=(16, 6, 1)))
+    eng = env._engine
+    table = np.random.randint(9, size=(16, 6)).astype(np.int32)
+    eng.upload_actions(table)
+    eng.policy_per_agent([_ffi.POLICY_ARGMAX, _ffi.POLICY_ARGMIN, _ffi.POLICY_TABLE, _ffi.POLICY_ARGMAX,
+                          _ffi.POLICY_TABLE, _ffi.POLICY_ARGMIN])
+    got = eng.download_actions()
+    gmax = amd.Greedy(epsilon=0.0)(obs)[..., 0]
+    gmin = amd.Greedy(epsilon=0.0, greedy=False)(obs)[..., 0]
+    want = np.stack([gmax[:, 0], gmin[:, 1], table[:, 2], gmax[:, 3], table[:, 4], gmin[:, 5]], axis=1)
+    assert np.array_equal(got, want)
+    env.close()

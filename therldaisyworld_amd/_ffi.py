@@ -77,6 +77,7 @@ SIGNATURES = {
     "dw_get_reward_done": (C.c_int, [_vp, _pd, _pu8]),
     "dw_reduce": (C.c_int, [_vp, C.POINTER(DwWorldStats)]),
     "dw_policy_greedy": (C.c_int, [_vp, C.c_int]),
+    "dw_policy_per_agent": (C.c_int, [_vp, _pi]),
     "dw_policy_mlp": (C.c_int, [_vp, _pd, _i32, _i32, _i32, _dbl]),
     "dw_policy_mlp_population": (C.c_int, [_vp, _pd, _i32, _pi, _i32, _i32, _dbl]),
     "dw_lifespan_reset": (C.c_int, [_vp]),

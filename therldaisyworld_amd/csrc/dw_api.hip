@@ -1072,8 +1072,31 @@ int dw_policy_greedy(dw_handle* h, int mode) {
          "device policy on an exact float64 initial state is not supported; compute the action on the host");
     hipLaunchKernelGGL(policy_greedy, dim3((bn + 255) / 256), dim3(256), 0, h->stream, h->L32[h->cur], h->D32[h->cur],
                        h->idx, p.batch, p.n_agents, p.height, p.width, p.obs_mask, mode == DW_POLICY_ARGMIN ? 1 : 0,
-                       h->action);
+                       (const int*)nullptr, h->action);
     HIPCHK(hipGetLastError());
+    return DW_OK;
+}
+
+int dw_policy_per_agent(dw_handle* h, const int32_t* agent_mode) {
+    NEED(h && agent_mode, DW_EINVAL, "null argument");
+    const dw_params& p = h->prm;
+    HIPCHK(hipSetDevice(p.device));
+    const int bn = p.batch * p.n_agents;
+    if (bn == 0) return DW_OK;
+    NEED(h->have_state && h->have_agents, DW_ESTATE, "no state / agents");
+    NEED(h->cur_quantised || h->f64 != F64_CUR, DW_ESTATE,
+         "device policy on an exact float64 initial state is not supported; compute the action on the host");
+    for (int n = 0; n < p.n_agents; ++n)
+        NEED(agent_mode[n] == DW_POLICY_ARGMAX || agent_mode[n] == DW_POLICY_ARGMIN || agent_mode[n] == DW_POLICY_TABLE,
+             DW_EINVAL, "agent %d: bad policy mode %d", n, agent_mode[n]);
+    // modes travel in the (otherwise idle) staging buffer of host-supplied actions; 3 -> internal code 2
+    std::vector<int> m(p.n_agents);
+    for (int n = 0; n < p.n_agents; ++n) m[n] = agent_mode[n] == DW_POLICY_TABLE ? 2 : agent_mode[n];
+    HIPCHK(hipMemcpyAsync(h->action_tmp, m.data(), sizeof(int) * p.n_agents, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(policy_greedy, dim3((bn + 255) / 256), dim3(256), 0, h->stream, h->L32[h->cur], h->D32[h->cur],
+                       h->idx, p.batch, p.n_agents, p.height, p.width, p.obs_mask, 0, h->action_tmp, h->action);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));      // `m` is a local host buffer
     return DW_OK;
 }
 

@@ -1575,12 +1575,19 @@ __global__ void observe(const PrevT* __restrict__ pL, const PrevT* __restrict__ 
 // action = 4 + argmax (or argmin), first extremum wins.  Reads the CURRENT covers directly
 // (ch1+ch2 of the post-step observation are exactly cur/1000).
 // ---------------------------------------------------------------------------------------------
+// `agent_mode` (optional, [N]): per agent index 0 = argmax, 1 = argmin, 2 = keep the action already in
+// the buffer (e.g. host-drawn random actions uploaded earlier) — mixed-policy ensembles (BASELINE C5).
 __global__ void policy_greedy(const float* __restrict__ cL, const float* __restrict__ cD,
                               const int* __restrict__ idx, int B, int N, int H, int W, int mask,
-                              int argmin, int* __restrict__ action) {
+                              int argmin, const int* __restrict__ agent_mode, int* __restrict__ action) {
     const int an = blockIdx.x * blockDim.x + threadIdx.x;
     if (an >= B * N) return;
     const int b = an / N;
+    if (agent_mode) {
+        const int m = agent_mode[an - b * N];
+        if (m == 2) return;
+        argmin = m == 1;
+    }
     const int ar = idx[(size_t)an * 2], ac = idx[(size_t)an * 2 + 1];
     const size_t woff = (size_t)b * H * W;
     const int cand[4] = {3, 1, 7, 5};

@@ -192,6 +192,13 @@ class Engine:
     def policy_greedy(self, argmin=False):
         check(self._lib.dw_policy_greedy(self._h, _ffi.POLICY_ARGMIN if argmin else _ffi.POLICY_ARGMAX))
 
+    def policy_per_agent(self, agent_mode):
+        """agent_mode (N,) of POLICY_ARGMAX / POLICY_ARGMIN / POLICY_TABLE (keep the uploaded action)."""
+        m = np.ascontiguousarray(agent_mode, dtype=np.int32)
+        if m.shape != (self.N,):
+            raise ValueError(f"agent_mode must have shape {(self.N,)}")
+        check(self._lib.dw_policy_per_agent(self._h, _ffi.ptr_i(m)))
+
     def policy_mlp(self, params, agent_begin=0, agent_end=None, L_init=0.75):
         w = np.ascontiguousarray(params, dtype=np.float64).ravel()
         end = self.N if agent_end is None else int(agent_end)
