@@ -838,3 +838,47 @@ def test_exact_mode_full_ramp_soak_vs_oracle(amd):
     s = eng.reduce()
     assert np.array_equal(s["sum_light_k"], _k(light).sum(axis=(1, 2)))
     eng.close()
+
+
+def test_dropin_side_effect_caches_match_reference_g2(amd, golden):
+    """env.temp / env.dead_temp / population means read through the drop-in's lazy attributes after each
+    step equal the reference's (fixture G2: seed 42, 64x64, no agents, first 40 steps)."""
+    g = golden("G2_c1_trajectory")
+    np.random.seed(42)
+    env = amd.RLDaisyWorld(grid_dimension=64, n_agents=0)
+    env.batch_size = 1
+    env.reset()
+    assert np.array_equal(env.grid[:, 1], g["light0"]) and np.array_equal(env.grid[:, 2], g["dark0"])
+    for t in range(40):
+        assert env.L == g["L_used"][t]
+        obs, reward, done, _ = env.step()
+        assert abs(env.temp.mean() - g["mean_temp"][t]) < 1e-9
+        assert env.dead_temp[0] == pytest.approx(g["dead_temp"][t], rel=1e-14)
+        assert env.grid[:, 1].mean() == g["mean_light"][t] and env.grid[:, 2].mean() == g["mean_dark"][t]
+        assert np.array_equal(reward, g["reward"][t]) and np.array_equal(done, g["done"][t])
+        assert env.beta.shape == (1, 1, 64, 64) and env.growth.shape == (1, 2, 64, 64)
+    env.close()
+
+
+def test_external_stream_and_event_timer(amd):
+    """dw_set_stream: the handle runs on a caller-owned HIP stream, results unchanged.  (The stream is made
+    with the HIP runtime the library itself links, through ctypes; torch's current stream works the same
+    way when torch initialised the device first, as bench.py does.)"""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    outs = []
+    for use_external in (False, True):
+        eng = _engine(amd, 2, 64, 128, 0, "exact")
+        if use_external:
+            stream = ctypes.c_void_p()
+            assert hip.hipStreamCreate(ctypes.byref(stream)) == 0
+            eng.set_stream(stream.value)
+        eng.init_random(4)
+        eng.timer_start()
+        L = eng.step_n(9, 0.9, 0.01, 0.75, 1.5)
+        ms = eng.timer_stop()
+        assert ms > 0.0
+        outs.append((L, eng.download_planes()))
+        eng.close()
+    assert outs[0][0] == outs[1][0]
+    assert np.array_equal(outs[0][1][0], outs[1][1][0]) and np.array_equal(outs[0][1][1], outs[1][1][1])
