@@ -11,7 +11,7 @@ It imports ``/root/reference/daisy`` (never copied into this repo), drives
 
   G1 forward()      G2 C1 trajectory      G3 scripted agents     G4 Greedy policy
   G5 lifespan sweep G6 ft_convolve pin    G7 no-agent path       G8 collision_mode=1
-  G9 constructor / reset RNG order
+  G9 constructor / reset RNG order      G10 MLP policy (seeded Glorot)   G11 the shipped trained MLP
 """
 import os
 import sys
@@ -330,10 +330,45 @@ def g10_mlp():
     save("G10_mlp", **out)
 
 
+def g11_trained_mlp():
+    """The trained policy the reference ships as a result file
+    (results/cmaes_exp_002/cmaes_exp_002_seed11_best_agent_gen127.json: 1808 weights + the 4 config keys of
+    MLP.make_config) loaded with MLP.set_parameters (the reference's restore_config raises, mlp.py:41) and
+    rolled out on the default 16x16 world.
+    Stored: the config (data), actions/rewards/dones per step, population means and the final grid."""
+    import json
+    from daisy.agents.mlp import MLP
+    path = os.path.join(REF, "results", "cmaes_exp_002", "cmaes_exp_002_seed11_best_agent_gen127.json")
+    with open(path) as f:
+        cfg = json.load(f)
+    np.random.seed(11)
+    agent = MLP()
+    agent.set_parameters(np.array(cfg["parameters"]))
+    env = RLDaisyWorld(grid_dimension=16, n_agents=4)
+    env.batch_size = 8
+    obs = env.reset()
+    out = {"in_dim": np.array(cfg["in_dim"]), "out_dim": np.array(cfg["out_dim"]),
+           "h_dim": np.array(cfg["h_dim"]), "act_name": np.array(cfg["act_name"]),
+           "parameters": np.array(cfg["parameters"], dtype=np.float64),
+           "restored_parameters": agent.get_parameters(),
+           "light0": env.grid[:, 1].copy(), "dark0": env.grid[:, 2].copy(),
+           "agent_indices0": env.agent_indices.copy(), "obs0": obs.copy()}
+    acts, rewards, dones, ml, md = [], [], [], [], []
+    for t in range(160):
+        a = agent(obs)
+        obs, reward, done, _ = env.step(a)
+        acts.append(a.astype(np.int8)); rewards.append(reward.copy()); dones.append(done.copy())
+        ml.append(env.grid[:, 1].mean(axis=(-2, -1))); md.append(env.grid[:, 2].mean(axis=(-2, -1)))
+    out.update(actions=np.array(acts), rewards=np.array(rewards), dones=np.array(dones),
+               mean_light=np.array(ml), mean_dark=np.array(md), grid_final=env.grid.copy(),
+               agent_indices_final=env.agent_indices.copy(), L_final=np.float64(env.L))
+    save("G11_trained_mlp", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
     fns = {"g1": g1_forward, "g2": g2_c1_trajectory, "g3": g3_agents, "g4": g4_greedy,
            "g5": g5_lifespans, "g6": g6_ft_convolve, "g7": g7_no_agents, "g8": g8_collisions,
-           "g9": g9_ctor_rng_order, "g10": g10_mlp}
+           "g9": g9_ctor_rng_order, "g10": g10_mlp, "g11": g11_trained_mlp}
     for w in which:
         fns[w]()

@@ -194,3 +194,25 @@ def test_host_mlp_mirror_matches_reference_fixture_g10(golden):
     clone = MLP()
     clone._apply_config(agent.make_config())
     assert np.array_equal(clone.get_parameters(), agent.get_parameters())
+
+
+def test_host_mlp_restores_the_shipped_result_file_g11(golden, tmp_path):
+    """A result file in the reference's format (in_dim/out_dim/h_dim/act_name/parameters) restores into
+    the mirror, survives a save/restore round trip, and reproduces the reference's first actions."""
+    import json
+    from therldaisyworld_amd import MLP
+    g = golden("G11_trained_mlp")
+    cfg = {"in_dim": int(g["in_dim"]), "out_dim": int(g["out_dim"]), "h_dim": [int(v) for v in g["h_dim"]],
+           "act_name": str(g["act_name"]), "parameters": [float(v) for v in g["parameters"]]}
+    path = tmp_path / "best_agent.json"
+    path.write_text(json.dumps(cfg))
+    agent = MLP()
+    agent.restore_config(str(path))
+    assert np.array_equal(agent.get_parameters(), g["restored_parameters"])
+    assert np.array_equal(agent(g["obs0"])[..., 0], g["actions"][0][..., 0])
+    again = tmp_path / "again.json"
+    agent.save_config(str(again))
+    clone = MLP()
+    clone.restore_config(str(again))
+    assert np.array_equal(clone.get_parameters(), agent.get_parameters())
+    assert sorted(clone.load_config(str(again)).keys()) == ["act_name", "h_dim", "in_dim", "out_dim", "parameters"]

@@ -682,6 +682,39 @@ def test_get_fitness_harness_matches_reference_rollout_g10(amd, golden):
     env.close(); env2.close()
 
 
+def test_trained_mlp_rollout_on_device_matches_reference_fixture_g11(amd, golden):
+    """The trained policy the reference ships (results/cmaes_exp_002, generation 127) on the default
+    16x16 world: policy_mlp on the device + step_device_actions for 160 steps reproduce the reference's
+    actions, rewards, per-world populations and final grid bit for bit."""
+    g = golden("G11_trained_mlp")
+    agent = amd.MLP()
+    agent.set_parameters(g["parameters"])
+    np.random.seed(11)
+    amd.MLP()                                                # the fixture drew one Glorot init before the env
+    env = amd.RLDaisyWorld(grid_dimension=16, n_agents=4)
+    env.batch_size = 8
+    obs = env.reset()
+    np.testing.assert_allclose(obs, g["obs0"], rtol=1e-12, atol=0)
+    assert np.array_equal(env.agent_indices, g["agent_indices0"])
+    eng = env._engine
+    for t in range(160):
+        agent.act_on_device(env)
+        assert np.array_equal(eng.download_actions()[..., None], g["actions"][t]), t
+        eng.step_device_actions(env.L)
+        env._L_pass = env.L
+        env._invalidate()
+        reward, done = eng.reward_done()
+        assert np.array_equal(reward * (reward > 0), g["rewards"][t]) and np.array_equal(done, g["dones"][t]), t
+        env.L = env.update_L(env.L)
+        if t % 16 == 15:
+            assert np.array_equal(env.grid[:, 1].mean(axis=(-2, -1)), g["mean_light"][t]), t
+            assert np.array_equal(env.grid[:, 2].mean(axis=(-2, -1)), g["mean_dark"][t]), t
+    assert np.array_equal(env.grid, g["grid_final"])
+    assert np.array_equal(env.agent_indices, g["agent_indices_final"])
+    assert env.L == float(g["L_final"])
+    env.close()
+
+
 # ---------------------------------------------------------------------------------------------
 # the exact mode's error bound, audited
 # ---------------------------------------------------------------------------------------------

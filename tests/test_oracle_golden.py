@@ -256,3 +256,25 @@ def test_g10_mlp_policy(golden):
         sum_reward += reward[:, :half].mean()
     assert sum_reward == float(g["sum_reward"])
     assert np.array_equal(env.grid, g["grid_final"])
+
+
+def test_g11_trained_mlp_rollout(golden):
+    """The trained policy the reference ships (CMA-ES generation 127), 160 steps on 8 default 16x16 worlds."""
+    g = golden("G11_trained_mlp")
+    agent = O.OracleMLP(g["parameters"])
+    env = _env(16, 4, 8)
+    env.set_initial_cover(g["light0"], g["dark0"])
+    env.agent_indices = g["agent_indices0"].copy()
+    env.agent_states = np.ones((8, 4, 1))
+    obs = env.get_obs(env.agent_indices)
+    np.testing.assert_allclose(obs, g["obs0"], rtol=1e-12, atol=0)
+    for t in range(160):
+        a = agent(obs)
+        assert np.array_equal(a, g["actions"][t]), t
+        obs, reward, done, _ = env.step(a)
+        assert np.array_equal(reward, g["rewards"][t]) and np.array_equal(done, g["dones"][t]), t
+        assert np.array_equal(env.grid[:, 1].mean(axis=(-2, -1)), g["mean_light"][t]), t
+        assert np.array_equal(env.grid[:, 2].mean(axis=(-2, -1)), g["mean_dark"][t]), t
+    assert np.array_equal(env.grid, g["grid_final"])
+    assert np.array_equal(env.agent_indices, g["agent_indices_final"])
+    assert env.L == float(g["L_final"])

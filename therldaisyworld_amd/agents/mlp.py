@@ -8,7 +8,12 @@ that hold NumPy observations; ``act_on_device(env, agent_begin, agent_end)`` eva
 HIP kernel (``policy_mlp``) straight from the device-resident state into the device action buffer, which is
 what ``therldaisyworld_amd.harness.get_fitness`` uses.
 """
+import json
+import os
+
 import numpy as np
+
+DEFAULT_CONFIG_PATH = os.path.join("results", "default_mlp_config.json")     # ref mlp.py:58,69,79
 
 
 def glorot(dims):
@@ -55,6 +60,21 @@ class MLP:
         self.initialize_parameters()
         if "parameters" in config:
             self.set_parameters(np.array(config["parameters"]))
+
+    def save_config(self, filepath=None):
+        """ref mlp.py:55-63: the config (with parameters) as one JSON object."""
+        with open(DEFAULT_CONFIG_PATH if filepath is None else filepath, "w") as f:
+            json.dump(self.make_config(), f)
+
+    def load_config(self, filepath=None):
+        """ref mlp.py:66-74"""
+        with open(DEFAULT_CONFIG_PATH if filepath is None else filepath, "r") as f:
+            return json.load(f)
+
+    def restore_config(self, filepath=None):
+        """ref mlp.py:76-83 (which raises in `_apply_config`, mlp.py:41; here it loads the file, so the
+        result files the reference ships, e.g. results/cmaes_exp_002/*_best_agent_gen127.json, restore)."""
+        self._apply_config(self.load_config(filepath))
 
     def forward(self, x):
         for layer in self.layers[:-1]:

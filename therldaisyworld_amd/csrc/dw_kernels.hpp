@@ -211,6 +211,47 @@ __device__ __forceinline__ Row4 load_row(const float* __restrict__ lds_row_group
     return r;
 }
 
+// The map on the four cells of one row group: (up, mid, down) rows of both planes -> new values (and,
+// in the exact mode, the near-tie flags).  Two cells per packed float32 lane pair (dw_physics.hpp).
+template <bool EXACT>
+__device__ __forceinline__ void cells4(const PhysF32& P, const Row4& upL, const Row4& miL, const Row4& dnL,
+                                       const Row4& upD, const Row4& miD, const Row4& dnD, float* ol, float* od,
+                                       bool* tie) {
+#pragma clang fp contract(off)
+#ifdef DW_SCALAR_CELLS
+    using T = float;
+#else
+    using T = dw_f32x2;
+#endif
+    constexpr int N = Lanes<T>::N;
+#pragma unroll
+    for (int i = 0; i < 4; i += N) {
+        auto pr = [&](const float* a) -> T { return Lanes<T>::load(a, i); };
+        const T li = pr(miL.x), di = pr(miD.x);
+        const T El = pr(miL.h2) + (pr(upL.x) + pr(dnL.x));
+        const T Cl = pr(upL.h2) + pr(dnL.h2);
+        const T Ed = pr(miD.h2) + (pr(upD.x) + pr(dnD.x));
+        const T Cd = pr(upD.h2) + pr(dnD.h2);
+        const GrowthT<T> g = growth_t<EXACT, T>(P, li, di, El, Cl, Ed, Cd);
+        T vl, vd;
+        if (EXACT) {
+            bool tl[N], td[N];
+            vl = finish_exact_t<T>(P, li, g.gql, g.dKl, g.oml, tl);
+            vd = finish_exact_t<T>(P, di, g.gqd, g.dKd, g.omd, td);
+#pragma unroll
+            for (int e = 0; e < N; ++e) tie[i + e] = tl[e] || td[e];
+        } else {
+            vl = finish_fast_t<T>(li, g.gql);
+            vd = finish_fast_t<T>(di, g.gqd);
+        }
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+            ol[i + e] = Lanes<T>::get(vl, e);
+            od[i + e] = Lanes<T>::get(vd, e);
+        }
+    }
+}
+
 #ifdef DW_TUNING
 // plain streaming copy of both planes: the achievable-bandwidth yardstick for this traffic shape
 __global__ __launch_bounds__(256) void copy_planes(const float4* __restrict__ inL, const float4* __restrict__ inD,
@@ -300,30 +341,26 @@ __global__ __launch_bounds__(256) void step_tiled(const float* __restrict__ inL,
                 const Row4 dnL = load_row(baseL + (row + 2) * C::LSTRIDE);
                 const Row4 dnD = load_row(baseD + (row + 2) * C::LSTRIDE);
                 float ol[4], od[4];
+                bool tie4[4] = {false, false, false, false};
                 unsigned int ties = 0;
+                cells4<EXACT>(P, upL, miL, dnL, upD, miD, dnD, ol, od, tie4);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float El = miL.h2[i] + (upL.x[i] + dnL.x[i]);
-                    const float Cl = upL.h2[i] + dnL.h2[i];
-                    const float Ed = miD.h2[i] + (upD.x[i] + dnD.x[i]);
-                    const float Cd = upD.h2[i] + dnD.h2[i];
 #ifdef DW_TUNING
-                    if (g_ablate == 1) { ol[i] = El + Cl; od[i] = Ed + Cd; continue; }
+                    if (g_ablate == 1) {
+                        ol[i] = (miL.h2[i] + upL.x[i] + dnL.x[i]) + (upL.h2[i] + dnL.h2[i]);
+                        od[i] = (miD.h2[i] + upD.x[i] + dnD.x[i]) + (upD.h2[i] + dnD.h2[i]);
+                        continue;
+                    }
 #endif
-                    const GrowthF32 g = growth_f32<EXACT>(P, miL.x[i], miD.x[i], El, Cl, Ed, Cd);
                     if (EXACT) {
-                        bool tl, td;
-                        ol[i] = finish_exact(P, miL.x[i], g.gql, g.dKl, g.oml, tl);
-                        od[i] = finish_exact(P, miD.x[i], g.gqd, g.dKd, g.omd, td);
-                        const bool tie = tl || td;
+                        const bool tie = tie4[i];
                         ties |= (tie ? 1u : 0u) << i;
                         // sums take the float32 value (the fix-up kernel adds the correction);
                         // the max cannot be corrected afterwards, so near-tie cells stay out of it
                         acc_l += ol[i]; acc_d += od[i];
                         acc_max = fmaxf(acc_max, tie ? 0.f : fmaxf(ol[i], od[i]));
                     } else {
-                        ol[i] = finish_fast(miL.x[i], g.gql);
-                        od[i] = finish_fast(miD.x[i], g.gqd);
                         acc_l += ol[i]; acc_d += od[i];
                         acc_max = fmaxf(acc_max, fmaxf(ol[i], od[i]));
                     }
@@ -714,22 +751,13 @@ __device__ __forceinline__ void stream_body(const float* __restrict__ inL, const
                         const Row4& dnD, int k) {
         float ol[4], od[4];
         bool tie[4];
+        cells4<EXACT>(P, upL, miL, dnL, upD, miD, dnD, ol, od, tie);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const float El = miL.h2[i] + (upL.x[i] + dnL.x[i]);
-            const float Cl = upL.h2[i] + dnL.h2[i];
-            const float Ed = miD.h2[i] + (upD.x[i] + dnD.x[i]);
-            const float Cd = upD.h2[i] + dnD.h2[i];
-            const GrowthF32 g = growth_f32<EXACT>(P, miL.x[i], miD.x[i], El, Cl, Ed, Cd);
             if (EXACT) {
-                bool tl, td;
-                ol[i] = finish_exact(P, miL.x[i], g.gql, g.dKl, g.oml, tl);
-                od[i] = finish_exact(P, miD.x[i], g.gqd, g.dKd, g.omd, td);
-                tie[i] = (tl || td) && (HALO != 2 || active);
+                tie[i] = tie[i] && (HALO != 2 || active);
                 acc_max = fmaxf(acc_max, tie[i] ? 0.f : fmaxf(ol[i], od[i]));
             } else {
-                ol[i] = finish_fast(miL.x[i], g.gql);
-                od[i] = finish_fast(miD.x[i], g.gqd);
                 acc_max = fmaxf(acc_max, fmaxf(ol[i], od[i]));
             }
             acc_l += ol[i]; acc_d += od[i];
@@ -972,22 +1000,10 @@ __device__ __forceinline__ void fused2_body(const float* __restrict__ inL, const
                        const Row4& miD, const Row4& dnD, float4& nl, float4& nd, int kind, int lrow, const bool* use) {
         float ol[4], od[4];
         bool tie[4];
+        cells4<EXACT>(P, upL, miL, dnL, upD, miD, dnD, ol, od, tie);
+        if (EXACT) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float El = miL.h2[i] + (upL.x[i] + dnL.x[i]);
-            const float Cl = upL.h2[i] + dnL.h2[i];
-            const float Ed = miD.h2[i] + (upD.x[i] + dnD.x[i]);
-            const float Cd = upD.h2[i] + dnD.h2[i];
-            const GrowthF32 g = growth_f32<EXACT>(P, miL.x[i], miD.x[i], El, Cl, Ed, Cd);
-            if (EXACT) {
-                bool tl, td;
-                ol[i] = finish_exact(P, miL.x[i], g.gql, g.dKl, g.oml, tl);
-                od[i] = finish_exact(P, miD.x[i], g.gqd, g.dKd, g.omd, td);
-                tie[i] = (tl || td) && use[i];
-            } else {
-                ol[i] = finish_fast(miL.x[i], g.gql);
-                od[i] = finish_fast(miD.x[i], g.gqd);
-            }
+            for (int i = 0; i < 4; ++i) tie[i] = tie[i] && use[i];
         }
         nl = make_float4(ol[0], ol[1], ol[2], ol[3]);
         nd = make_float4(od[0], od[1], od[2], od[3]);

@@ -162,79 +162,137 @@ struct PhysF32 {
     float tie_lo, eA, eK0, eK1;
 };
 
-struct GrowthF32 {
-    float gql, gqd;              // per-mille growth dt*K*(kb*beta - gamma) for light, dark
-    float dKl, dKd;              // dt * density (per-mille), used by the tie bound
-    float oml, omd;              // 1 - beta_l, 1 - beta_d (>= 0), used by the tie bound
+// The float32 algebra is written once, generic in the lane type T: float (one cell) or dw_f32x2 (two
+// horizontally adjacent cells).  On gfx950 the two-cell form compiles to packed float32 instructions
+// (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two IEEE operations per lane per issue slot), which is what
+// the wave-strip kernels are bound by; transcendentals, rint and the clamp stay one instruction per cell.
+// Floating-point contraction is switched off and every fused multiply-add is spelled out, so both
+// instantiations perform the SAME correctly-rounded operations in the same order: all kernels produce
+// bit-identical values whichever form they use.
+typedef float dw_f32x2 __attribute__((ext_vector_type(2)));
+
+template <typename T> struct Lanes;
+template <> struct Lanes<float> {
+    static constexpr int N = 1;
+    static __device__ __forceinline__ float fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+    static __device__ __forceinline__ float sqrt(float v) { return __builtin_amdgcn_sqrtf(v); }
+    static __device__ __forceinline__ float rcp(float v) { return __builtin_amdgcn_rcpf(v); }
+    static __device__ __forceinline__ float rint(float v) { return __builtin_rintf(v); }
+    static __device__ __forceinline__ float abs(float v) { return __builtin_fabsf(v); }
+    static __device__ __forceinline__ float clip(float v) { return fminf(fmaxf(v, 0.0f), 1000.0f); }
+    static __device__ __forceinline__ float get(float v, int) { return v; }
+    static __device__ __forceinline__ void gt(float a, float b, bool* out) { out[0] = a > b; }
+    static __device__ __forceinline__ float load(const float* a, int i) { return a[i]; }
 };
+template <> struct Lanes<dw_f32x2> {
+    static constexpr int N = 2;
+    using T = dw_f32x2;
+    static __device__ __forceinline__ T fma(T a, T b, T c) { return __builtin_elementwise_fma(a, b, c); }
+    static __device__ __forceinline__ T sqrt(T v) { return T{__builtin_amdgcn_sqrtf(v.x), __builtin_amdgcn_sqrtf(v.y)}; }
+    static __device__ __forceinline__ T rcp(T v) { return T{__builtin_amdgcn_rcpf(v.x), __builtin_amdgcn_rcpf(v.y)}; }
+    static __device__ __forceinline__ T rint(T v) { return T{__builtin_rintf(v.x), __builtin_rintf(v.y)}; }
+    static __device__ __forceinline__ T abs(T v) { return T{__builtin_fabsf(v.x), __builtin_fabsf(v.y)}; }
+    static __device__ __forceinline__ T clip(T v) {
+        return T{fminf(fmaxf(v.x, 0.0f), 1000.0f), fminf(fmaxf(v.y, 0.0f), 1000.0f)};
+    }
+    static __device__ __forceinline__ float get(T v, int i) { return i == 0 ? v.x : v.y; }
+    static __device__ __forceinline__ void gt(T a, T b, bool* out) { out[0] = a.x > b.x; out[1] = a.y > b.y; }
+    static __device__ __forceinline__ T load(const float* a, int i) { return T{a[i], a[i + 1]}; }
+};
+
+template <typename T>
+struct GrowthT {
+    T gql, gqd;                  // per-mille growth dt*K*(kb*beta - gamma) for light, dark
+    T dKl, dKd;                  // dt * density (per-mille), used by the tie bound
+    T oml, omd;                  // 1 - beta_l, 1 - beta_d (>= 0), used by the tie bound
+};
+using GrowthF32 = GrowthT<float>;
 
 // El/Cl: sums of the 4 edge / 4 corner neighbours of light; Ed/Cd of dark; li/di the centre.
 // SPLIT = true: hi/lo coefficient chains (exact mode: its tie bound relies on the exact hi chain).
 // SPLIT = false: one float32 coefficient each (float32-only mode: 6 instructions fewer per cell).
-template <bool SPLIT = true>
-__device__ __forceinline__ GrowthF32 growth_f32(const PhysF32& P, float li, float di, float El,
-                                                float Cl, float Ed, float Cd) {
-    const float Sl8 = El + Cl, Sd8 = Ed + Cd;
-    float el, ed;
+template <bool SPLIT, typename T>
+__device__ __forceinline__ GrowthT<T> growth_t(const PhysF32& P, T li, T di, T El, T Cl, T Ed, T Cd) {
+#pragma clang fp contract(off)
+    using V = Lanes<T>;
+    const T one = T(1.0f);
+    const T Sl8 = El + Cl, Sd8 = Ed + Cd;
+    T el, ed;
     if (SPLIT) {
-        float hi = P.a1h * Sl8;
-        hi = fmaf(P.a2h, Sd8, hi);
-        hi = fmaf(P.a3h, li, hi);
-        hi = fmaf(P.a4h, di, hi);
-        float lo = P.a1l * Sl8;
-        lo = fmaf(P.a2l, Sd8, lo);
-        lo = fmaf(P.a3l, li, lo);
-        lo = fmaf(P.a4l, di, lo);
-        el = (hi + P.c0lh) + (lo + P.c0ll);
-        ed = (hi + P.c0dh) + (lo + P.c0dl);
+        T hi = T(P.a1h) * Sl8;
+        hi = V::fma(T(P.a2h), Sd8, hi);
+        hi = V::fma(T(P.a3h), li, hi);
+        hi = V::fma(T(P.a4h), di, hi);
+        T lo = T(P.a1l) * Sl8;
+        lo = V::fma(T(P.a2l), Sd8, lo);
+        lo = V::fma(T(P.a3l), li, lo);
+        lo = V::fma(T(P.a4l), di, lo);
+        el = (hi + T(P.c0lh)) + (lo + T(P.c0ll));
+        ed = (hi + T(P.c0dh)) + (lo + T(P.c0dl));
     } else {
-        float base = (P.a1h + P.a1l) * Sl8;                 // coefficient sums are wave-uniform (hoisted)
-        base = fmaf(P.a2h + P.a2l, Sd8, base);
-        base = fmaf(P.a3h + P.a3l, li, base);
-        base = fmaf(P.a4h + P.a4l, di, base);
-        el = base + (P.c0lh + P.c0ll);
-        ed = base + (P.c0dh + P.c0dl);
+        T base = T(P.a1h + P.a1l) * Sl8;                    // coefficient sums are wave-uniform (hoisted)
+        base = V::fma(T(P.a2h + P.a2l), Sd8, base);
+        base = V::fma(T(P.a3h + P.a3l), li, base);
+        base = V::fma(T(P.a4h + P.a4l), di, base);
+        el = base + T(P.c0lh + P.c0ll);
+        ed = base + T(P.c0dh + P.c0dl);
     }
     // light
-    const float sl = __builtin_amdgcn_sqrtf(1.0f + el);
-    const float yl = __builtin_amdgcn_sqrtf(sl);
-    const float dl = el * __builtin_amdgcn_rcpf((yl + 1.0f) * (sl + 1.0f));
-    const float oml = (P.cbeta * dl) * dl;
-    const float bl = 1.0f - oml;
+    const T sl = V::sqrt(one + el);
+    const T yl = V::sqrt(sl);
+    const T dl = el * V::rcp((yl + one) * (sl + one));
+    const T cdl = T(P.cbeta) * dl;
+    const T bl = V::fma(-cdl, dl, one);                     // beta_l = 1 - cbeta*dl^2
     // dark
-    const float sd = __builtin_amdgcn_sqrtf(1.0f + ed);
-    const float yd = __builtin_amdgcn_sqrtf(sd);
-    const float dd = ed * __builtin_amdgcn_rcpf((yd + 1.0f) * (sd + 1.0f));
-    const float omd = (P.cbeta * dd) * dd;
-    const float bd = 1.0f - omd;
+    const T sd = V::sqrt(one + ed);
+    const T yd = V::sqrt(sd);
+    const T dd = ed * V::rcp((yd + one) * (sd + one));
+    const T cdd = T(P.cbeta) * dd;
+    const T bd = V::fma(-cdd, dd, one);
     // densities (per-mille) and bare fraction (natural)
-    const float Kl = fmaf(P.w2, Cl, fmaf(P.w1, El, P.w0 * li));
-    const float Kd = fmaf(P.w2, Cd, fmaf(P.w1, Ed, P.w0 * di));
-    const float kb = fmaf(-(Kl + Kd), 0.001f, P.p);
-    GrowthF32 o;
-    o.oml = oml;
-    o.omd = omd;
-    o.dKl = P.dt * Kl;
-    o.dKd = P.dt * Kd;
-    o.gql = o.dKl * fmaf(kb, bl, -P.gamma);
-    o.gqd = o.dKd * fmaf(kb, bd, -P.gamma);
+    const T Kl = V::fma(T(P.w2), Cl, V::fma(T(P.w1), El, T(P.w0) * li));
+    const T Kd = V::fma(T(P.w2), Cd, V::fma(T(P.w1), Ed, T(P.w0) * di));
+    const T kb = V::fma(-(Kl + Kd), T(0.001f), T(P.p));
+    GrowthT<T> o;
+    o.oml = cdl * dl;                                       // only the exact mode's tie bound reads these
+    o.omd = cdd * dd;
+    o.dKl = T(P.dt) * Kl;
+    o.dKd = T(P.dt) * Kd;
+    o.gql = o.dKl * V::fma(kb, bl, T(-P.gamma));
+    o.gqd = o.dKd * V::fma(kb, bd, T(-P.gamma));
     return o;
 }
 
-// FAST finaliser: k' = rint(clip(k + gq, 0, 1000)) — valid for any (also un-quantised) input.
-__device__ __forceinline__ float finish_fast(float k, float gq) {
-    return __builtin_rintf(fminf(fmaxf(k + gq, 0.0f), 1000.0f));
+template <bool SPLIT = true>
+__device__ __forceinline__ GrowthF32 growth_f32(const PhysF32& P, float li, float di, float El, float Cl,
+                                                float Ed, float Cd) {
+    return growth_t<SPLIT, float>(P, li, di, El, Cl, Ed, Cd);
 }
 
+// FAST finaliser: k' = rint(clip(k + gq, 0, 1000)) — valid for any (also un-quantised) input.
+template <typename T>
+__device__ __forceinline__ T finish_fast_t(T k, T gq) {
+#pragma clang fp contract(off)
+    return Lanes<T>::rint(Lanes<T>::clip(k + gq));
+}
+__device__ __forceinline__ float finish_fast(float k, float gq) { return finish_fast_t<float>(k, gq); }
+
 // EXACT finaliser for an integer k: rint(k + gq) = k + rint(gq) unless gq is within the float32
-// error bound of a tie, in which case `tie` is raised and the caller re-evaluates in float64.
-__device__ __forceinline__ float finish_exact(const PhysF32& P, float k, float gq, float dK,
-                                              float om, bool& tie) {
-    const float r = __builtin_rintf(gq);
-    const float frac = fabsf(gq - r);                       // exact (Sterbenz)
-    const float thr = fmaf(-fabsf(dK), fmaf(P.eK1, om, P.eK0), fmaf(-P.eA, fabsf(gq), P.tie_lo));
-    tie = frac > thr;
-    return fminf(fmaxf(k + r, 0.0f), 1000.0f);
+// error bound of a tie, in which case the cell's `tie` flag (one per lane of T) is raised and the caller
+// re-evaluates in float64.
+template <typename T>
+__device__ __forceinline__ T finish_exact_t(const PhysF32& P, T k, T gq, T dK, T om, bool* tie) {
+#pragma clang fp contract(off)
+    using V = Lanes<T>;
+    const T r = V::rint(gq);
+    const T frac = V::abs(gq - r);                          // exact (Sterbenz)
+    const T thr = V::fma(-V::abs(dK), V::fma(T(P.eK1), om, T(P.eK0)), V::fma(T(-P.eA), V::abs(gq), T(P.tie_lo)));
+    V::gt(frac, thr, tie);
+    return V::clip(k + r);
+}
+__device__ __forceinline__ float finish_exact(const PhysF32& P, float k, float gq, float dK, float om,
+                                              bool& tie) {
+    return finish_exact_t<float>(P, k, gq, dK, om, &tie);
 }
 
 // Philox4x32-10 (Salmon et al., SC'11) — counter-based RNG for the synthetic initial states.
