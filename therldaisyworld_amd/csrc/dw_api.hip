@@ -156,7 +156,7 @@ static void split_hi_lo(double v, double scale, float* hi, float* lo) {
 
 // Derivation of the fused float32 coefficients (see dw_physics.hpp, PhysF32) and of the exact-mode
 // tie bound (DESIGN.md §"Exact mode").  All in float64, rounded once.
-static PhysF32 derive_f32(const dw_params& p, double L) {
+static PhysF32 derive_f32(const dw_params& p, double L, int hb_cap = 40) {
     const double To4 = std::pow(p.temp_optimal, 4);
     const double K = p.S * L / p.sigma;
     const double dal = p.albedo_light - p.albedo_bare, dad = p.albedo_dark - p.albedo_bare;
@@ -173,10 +173,11 @@ static PhysF32 derive_f32(const dw_params& p, double L) {
     const double maxsum = std::fabs(a1) * 8 * kmax + std::fabs(a2) * 8 * kmax + std::fabs(a3) * kmax +
                           std::fabs(a4) * kmax + std::fmax(std::fabs(c0l), std::fabs(c0d));
     int hb = 23 - (int)std::ceil(std::log2(std::fmax(maxsum, 1e-30)));
-    if (hb > 40) hb = 40;
+    if (hb > hb_cap) hb = hb_cap;                               // a coarser split is always admissible
     if (hb < 0) hb = 0;
     const double scale = std::ldexp(1.0, hb);
     PhysF32 P;
+    P.hi_bits = hb;
     split_hi_lo(a1, scale, &P.a1h, &P.a1l);
     split_hi_lo(a2, scale, &P.a2h, &P.a2l);
     split_hi_lo(a3, scale, &P.a3h, &P.a3l);
@@ -207,6 +208,19 @@ static PhysF32 derive_f32(const dw_params& p, double L) {
     P.eK0 = (float)(safety * 5.0 * u);
     P.eK1 = (float)(safety * 28.0 * u);
     return P;
+}
+
+// Coefficient sets of the two steps of a fused exact launch, split at the SAME scale (the coarser of
+// the two) and with the more conservative of the two tie thresholds: they then differ only in the
+// luminosity-dependent members (PhysLumF32).
+static void derive_f32_pair(const dw_params& p, double L1, double L2, PhysF32* P1, PhysF32* P2) {
+    const PhysF32 a = derive_f32(p, L1), b = derive_f32(p, L2);
+    const int hb = a.hi_bits < b.hi_bits ? a.hi_bits : b.hi_bits;
+    *P1 = derive_f32(p, L1, hb);
+    *P2 = derive_f32(p, L2, hb);
+    const float tie_lo = P1->tie_lo < P2->tie_lo ? P1->tie_lo : P2->tie_lo;
+    P1->tie_lo = tie_lo;
+    P2->tie_lo = tie_lo;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -372,9 +386,11 @@ static int launch_forward(dw_handle* h, double L) {
     hipLaunchKernelGGL((K<HL>), grid, dim3(256), 0, h->stream, h->L32[in], h->D32[in], h->L32[out],     \
                        h->D32[out], g, P, P64, stats, fixups, zero_me, zero_n)
         if (ex) {
-            if (halo == 0) DW_STREAM(step_stream_exact, 0);
-            else if (halo == 1) DW_STREAM(step_stream_exact, 1);
-            else DW_STREAM(step_stream_exact, 2);
+            const StreamExactArgs A{h->L32[in], h->D32[in], h->L32[out], h->D32[out], g, P, stats, fixups, zero_me,
+                                    zero_n, P64};
+            if (halo == 0) hipLaunchKernelGGL((step_stream_exact<0>), grid, dim3(256), 0, h->stream, A);
+            else if (halo == 1) hipLaunchKernelGGL((step_stream_exact<1>), grid, dim3(256), 0, h->stream, A);
+            else hipLaunchKernelGGL((step_stream_exact<2>), grid, dim3(256), 0, h->stream, A);
         } else {
             if (halo == 0) DW_STREAM(step_stream_fast, 0);
             else if (halo == 1) DW_STREAM(step_stream_fast, 1);
@@ -413,20 +429,19 @@ static int launch_forward(dw_handle* h, double L) {
 static int launch_forward_fused2(dw_handle* h, double L1, double L2) {
     const dw_params& p = h->prm;
     const int in = h->cur, out = 1 - h->cur;
-    const PhysF32 P1 = derive_f32(p, L1), P2 = derive_f32(p, L2);
+    PhysF32 P1, P2;
+    if (p.precision == DW_PRECISION_EXACT) derive_f32_pair(p, L1, L2, &P1, &P2);
+    else { P1 = derive_f32(p, L1); P2 = derive_f32(p, L2); }
     unsigned long long* zero_me = reinterpret_cast<unsigned long long*>(h->stats2[h->sp]);
     const int zero_n = (int)(h->stats_bytes / sizeof(unsigned long long));
     const FusedGeom& g = h->fgeom;
     const dim3 grid((unsigned)g.chunk * 8u);
     const bool rot = p.width == 256;
     if (p.precision == DW_PRECISION_EXACT) {
-        const PhysF64 P64 = make_f64(p, L1);
-        if (rot)
-            hipLaunchKernelGGL((step_stream_fused2_exact<true>), grid, dim3(256), 0, h->stream, h->L32[in], h->D32[in],
-                               h->L32[out], h->D32[out], g, P1, P2, P64, L1, L2, zero_me, zero_n);
-        else
-            hipLaunchKernelGGL((step_stream_fused2_exact<false>), grid, dim3(256), 0, h->stream, h->L32[in], h->D32[in],
-                               h->L32[out], h->D32[out], g, P1, P2, P64, L1, L2, zero_me, zero_n);
+        const FusedExactArgs A{h->L32[in], h->D32[in], h->L32[out], h->D32[out], g, P1, lum_part(P2), zero_me, zero_n,
+                               make_f64(p, L1), L1, L2};
+        if (rot) hipLaunchKernelGGL((step_stream_fused2_exact<true>), grid, dim3(256), 0, h->stream, A);
+        else hipLaunchKernelGGL((step_stream_fused2_exact<false>), grid, dim3(256), 0, h->stream, A);
     } else {
         if (rot)
             hipLaunchKernelGGL((step_stream_fused2<true>), grid, dim3(256), 0, h->stream, h->L32[in], h->D32[in],

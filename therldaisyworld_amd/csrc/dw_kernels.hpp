@@ -647,6 +647,15 @@ __device__ __forceinline__ Row4 make_row(const float4& v, float lnb, float rnb) 
 
 // the three (light | dark << 16) words of columns i-1, i, i+1 of one window row; the column left of
 // x[0] is h2[0] - x[1] and the one right of x[3] is h2[3] - x[2] (exact: all values are integers)
+// Wave-queue payload word: one (light, dark) pair of per-mille integers in [0, 1000] as the BITS of the
+// float light + 1024*dark (exact: < 2^24) - one fma on the producer side, which runs for every lane of a
+// wave that holds a near-tie cell; the few consumer lanes decode it back to light | dark << 16.
+__device__ __forceinline__ unsigned int pack_ld(float l, float d) { return __float_as_uint(__builtin_fmaf(d, 1024.0f, l)); }
+__device__ __forceinline__ unsigned int unpack_ld(unsigned int bits) {
+    const unsigned int v = (unsigned int)__uint_as_float(bits);
+    return (v & 1023u) | ((v >> 10) << 16);
+}
+
 template <int I>
 __device__ __forceinline__ void pack3(const Row4& L, const Row4& D, unsigned int& w0, unsigned int& w1,
                                       unsigned int& w2) {
@@ -654,9 +663,9 @@ __device__ __forceinline__ void pack3(const Row4& L, const Row4& D, unsigned int
     const float da = I == 0 ? D.h2[0] - D.x[1] : D.x[I == 0 ? 0 : I - 1];
     const float lc = I == 3 ? L.h2[3] - L.x[2] : L.x[I == 3 ? 3 : I + 1];
     const float dc = I == 3 ? D.h2[3] - D.x[2] : D.x[I == 3 ? 3 : I + 1];
-    w0 = (unsigned)la | ((unsigned)da << 16);
-    w1 = (unsigned)L.x[I] | ((unsigned)D.x[I] << 16);
-    w2 = (unsigned)lc | ((unsigned)dc << 16);
+    w0 = pack_ld(la, da);
+    w1 = pack_ld(L.x[I], D.x[I]);
+    w2 = pack_ld(lc, dc);
 }
 
 constexpr int kWaveQueueCap = 256;          // near-tie entries per wave-strip held in LDS (48 B each)
@@ -679,7 +688,7 @@ __device__ __forceinline__ void queue_tie(bool tie, unsigned int& n, uint4* __re
             uint4* dst = q + slot * 3;
             dst[0] = make_uint4((unsigned)b, ((unsigned)row << 16) | (unsigned)(colq + I), u0, u1);
             dst[1] = make_uint4(u2, m0, m1, m2);
-            dst[2] = make_uint4(d0, d1, d2, (unsigned)ol[I] | ((unsigned)od[I] << 16));
+            dst[2] = make_uint4(d0, d1, d2, pack_ld(ol[I], od[I]));
         }
     }
     n += (unsigned)__popcll(mask);
@@ -798,14 +807,17 @@ __device__ __forceinline__ void stream_body(const float* __restrict__ inL, const
         if (nq <= (unsigned)G.qcap) {
             for (unsigned int e = lane; e < nq; e += 64) {
                 const uint4 e0 = q[e * 3], e1 = q[e * 3 + 1], e2 = q[e * 3 + 2];
-                const unsigned int w[9] = {e0.z, e0.w, e1.x, e1.y, e1.z, e1.w, e2.x, e2.y, e2.z};
+                const unsigned int w[9] = {unpack_ld(e0.z), unpack_ld(e0.w), unpack_ld(e1.x),
+                                           unpack_ld(e1.y), unpack_ld(e1.z), unpack_ld(e1.w),
+                                           unpack_ld(e2.x), unpack_ld(e2.y), unpack_ld(e2.z)};
+                const unsigned int f32v = unpack_ld(e2.w);
                 const NewCoverF64 o = cell_f64_lean(P64, w);
                 const float kl = (float)dw_round3_k(o.nl), kd = (float)dw_round3_k(o.nd);
                 const size_t off = woff + (size_t)(e0.y >> 16) * G.W + (e0.y & 0xffffu);
                 outL[off] = kl;                             // after this wave's own float4 store of the row
                 outD[off] = kd;
-                acc_l += kl - (float)(e2.w & 0xffffu);
-                acc_d += kd - (float)(e2.w >> 16);
+                acc_l += kl - (float)(f32v & 0xffffu);
+                acc_d += kd - (float)(f32v >> 16);
                 acc_max = fmaxf(acc_max, fmaxf(kl, kd));
             }
         } else {                                            // queue overflow: the whole strip in float64
@@ -853,12 +865,27 @@ __global__ __launch_bounds__(256) void step_stream_fast(const float* __restrict_
     stream_body<false, HALO, DW_STREAM_RB_FAST>(inL, inD, outL, outD, G, P, P64, stats, fixups, zero_me, zero_n);
 }
 
+// The exact kernels' float64 constants are needed only by the rare repair code after the strip loop.
+// Taken as ordinary by-value arguments they are loaded into SGPRs at kernel entry and stay live through
+// the loop, which then runs out of SGPRs (92-190 scalar spills, a v_readlane per use).  So the exact
+// kernels take ONE argument struct, and the cold members are read from the kernarg segment at their use.
+template <typename A>
+__device__ __forceinline__ const A& kernarg_struct() {          // A is the kernel's only argument: offset 0
+    return *reinterpret_cast<const A*>((const void*)__builtin_amdgcn_kernarg_segment_ptr());
+}
+
+struct StreamExactArgs {
+    const float* inL; const float* inD; float* outL; float* outD;
+    StripGeom G; PhysF32 P; StatsDev* stats; unsigned long long* fixups; unsigned long long* zero_me; int zero_n;
+    PhysF64 P64;                                                  // cold
+};
+
 template <int HALO>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DW_STREAM_WAVES_EXACT, DW_STREAM_WAVES_EXACT)))
-void step_stream_exact(const float* __restrict__ inL, const float* __restrict__ inD, float* __restrict__ outL,
-                       float* __restrict__ outD, StripGeom G, PhysF32 P, PhysF64 P64, StatsDev* __restrict__ stats,
-                       unsigned long long* __restrict__ fixups, unsigned long long* __restrict__ zero_me, int zero_n) {
-    stream_body<true, HALO, DW_STREAM_RB_EXACT>(inL, inD, outL, outD, G, P, P64, stats, fixups, zero_me, zero_n);
+void step_stream_exact(StreamExactArgs A) {
+    stream_body<true, HALO, DW_STREAM_RB_EXACT>(A.inL, A.inD, A.outL, A.outD, A.G, A.P,
+                                                kernarg_struct<StreamExactArgs>().P64, A.stats, A.fixups, A.zero_me,
+                                                A.zero_n);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -933,8 +960,9 @@ constexpr int kMismatchCap = 64;            // float32 step-1 mismatches per wav
 template <bool ROT, bool EXACT>
 __device__ __forceinline__ void fused2_body(const float* __restrict__ inL, const float* __restrict__ inD,
                                             float* __restrict__ outL, float* __restrict__ outD, const FusedGeom& G,
-                                            const PhysF32& P1, const PhysF32& P2, const PhysF64& P64, double La,
-                                            double Lb, unsigned long long* __restrict__ zero_me, int zero_n) {
+                                            const PhysF32& P1, const PhysF32& P2, const PhysF64& P64,
+                                            const double& La, const double& Lb,
+                                            unsigned long long* __restrict__ zero_me, int zero_n) {
     __shared__ uint4 s_queue[EXACT ? 4 * kWaveQueueCap * 3 : 1];
     __shared__ unsigned int s_mm[EXACT ? 4 * kMismatchCap : 1];
     const int bid = blockIdx.x;
@@ -1088,10 +1116,12 @@ __device__ __forceinline__ void fused2_body(const float* __restrict__ inL, const
                 if (e < nq) {
                     const uint4 e0 = q[e * 3], e1 = q[e * 3 + 1], e2 = q[e * 3 + 2];
                     if (e0.x == 1u) {
-                        const unsigned int w[9] = {e0.z, e0.w, e1.x, e1.y, e1.z, e1.w, e2.x, e2.y, e2.z};
+                        const unsigned int w[9] = {unpack_ld(e0.z), unpack_ld(e0.w), unpack_ld(e1.x),
+                                                   unpack_ld(e1.y), unpack_ld(e1.z), unpack_ld(e1.w),
+                                                   unpack_ld(e2.x), unpack_ld(e2.y), unpack_ld(e2.z)};
                         const NewCoverF64 o = cell_f64_lean(Pa, w);
                         const unsigned int exact = (unsigned)dw_round3_k(o.nl) | ((unsigned)dw_round3_k(o.nd) << 16);
-                        mism = exact != e2.w;
+                        mism = exact != unpack_ld(e2.w);
                         where = e0.y;
                     }
                 }
@@ -1111,7 +1141,9 @@ __device__ __forceinline__ void fused2_body(const float* __restrict__ inL, const
             for (unsigned int e = lane; e < nq; e += 64) {
                 const uint4 e0 = q[e * 3], e1 = q[e * 3 + 1], e2 = q[e * 3 + 2];
                 if (e0.x != 2u) continue;
-                const unsigned int w[9] = {e0.z, e0.w, e1.x, e1.y, e1.z, e1.w, e2.x, e2.y, e2.z};
+                const unsigned int w[9] = {unpack_ld(e0.z), unpack_ld(e0.w), unpack_ld(e1.x),
+                                           unpack_ld(e1.y), unpack_ld(e1.z), unpack_ld(e1.w),
+                                           unpack_ld(e2.x), unpack_ld(e2.y), unpack_ld(e2.z)};
                 const NewCoverF64 o = cell_f64_lean(Pb, w);
                 int gr, gc;
                 grid_rc((int)(e0.y >> 16), (int)(e0.y & 0xffffu), gr, gc);
@@ -1158,19 +1190,31 @@ __global__ __launch_bounds__(256) void step_stream_fused2(const float* __restric
                                                           float* __restrict__ outL, float* __restrict__ outD,
                                                           FusedGeom G, PhysF32 P1, PhysF32 P2,
                                                           unsigned long long* __restrict__ zero_me, int zero_n) {
-    PhysF64 dummy{};
-    fused2_body<ROT, false>(inL, inD, outL, outD, G, P1, P2, dummy, 0.0, 0.0, zero_me, zero_n);
+    const PhysF64 dummy{};
+    const double zero = 0.0;
+    fused2_body<ROT, false>(inL, inD, outL, outD, G, P1, P2, dummy, zero, zero, zero_me, zero_n);
 }
 
 #ifndef DW_FUSED_EXACT_WAVES
 #define DW_FUSED_EXACT_WAVES 2
 #endif
+struct FusedExactArgs {
+    const float* inL; const float* inD; float* outL; float* outD;
+    FusedGeom G;
+    PhysF32 P1; PhysLumF32 lum2;                                  // step 2 = P1 with these members replaced:
+                                                                  // 15 shared constants instead of 2 x 23 (each
+                                                                  // one occupies an SGPR PAIR as a packed operand)
+    unsigned long long* zero_me; int zero_n;
+    PhysF64 P64; double La; double Lb;                            // cold (see kernarg_struct)
+};
+
 template <bool ROT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DW_FUSED_EXACT_WAVES, DW_FUSED_EXACT_WAVES)))
-void step_stream_fused2_exact(const float* __restrict__ inL, const float* __restrict__ inD, float* __restrict__ outL,
-                              float* __restrict__ outD, FusedGeom G, PhysF32 P1, PhysF32 P2, PhysF64 P64, double La,
-                              double Lb, unsigned long long* __restrict__ zero_me, int zero_n) {
-    fused2_body<ROT, true>(inL, inD, outL, outD, G, P1, P2, P64, La, Lb, zero_me, zero_n);
+void step_stream_fused2_exact(FusedExactArgs A) {
+    const FusedExactArgs& cold = kernarg_struct<FusedExactArgs>();
+    const PhysF32 P2 = with_lum(A.P1, A.lum2);
+    fused2_body<ROT, true>(A.inL, A.inD, A.outL, A.outD, A.G, A.P1, P2, cold.P64, cold.La, cold.Lb, A.zero_me,
+                           A.zero_n);
 }
 
 // ---------------------------------------------------------------------------------------------

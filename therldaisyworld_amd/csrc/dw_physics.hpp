@@ -160,7 +160,22 @@ struct PhysF32 {
     // exact-mode tie test (per-mille; om = 1 - beta = cbeta*((T-To)/To)^2 >= 0):
     //   |frac(gq)| > tie_lo - eA*|gq| - |dt*K|*(eK0 + eK1*om)   =>  re-evaluate in float64
     float tie_lo, eA, eK0, eK1;
+    int hi_bits;                 // the hi parts are multiples of 2^-hi_bits (host bookkeeping)
 };
+
+// the members of PhysF32 that depend on the luminosity (the rest is shared by the two steps of a fused
+// launch when both coefficient sets are split at the same scale, see derive_f32_pair() in dw_api.hip)
+struct PhysLumF32 {
+    float a1h, a2h, a1l, a2l, c0lh, c0ll, c0dh, c0dl;
+};
+__host__ __device__ inline PhysLumF32 lum_part(const PhysF32& P) {
+    return PhysLumF32{P.a1h, P.a2h, P.a1l, P.a2l, P.c0lh, P.c0ll, P.c0dh, P.c0dl};
+}
+__host__ __device__ inline PhysF32 with_lum(PhysF32 P, const PhysLumF32& l) {
+    P.a1h = l.a1h; P.a2h = l.a2h; P.a1l = l.a1l; P.a2l = l.a2l;
+    P.c0lh = l.c0lh; P.c0ll = l.c0ll; P.c0dh = l.c0dh; P.c0dl = l.c0dl;
+    return P;
+}
 
 // The float32 algebra is written once, generic in the lane type T: float (one cell) or dw_f32x2 (two
 // horizontally adjacent cells).  On gfx950 the two-cell form compiles to packed float32 instructions
