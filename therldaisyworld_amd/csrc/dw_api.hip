@@ -207,6 +207,8 @@ static PhysF32 derive_f32(const dw_params& p, double L, int hb_cap = 40) {
     P.eA = (float)(safety * 9.0 * u);
     P.eK0 = (float)(safety * 5.0 * u);
     P.eK1 = (float)(safety * 28.0 * u);
+    P.eK0s = p.dt < 0.0 ? P.eK0 : -P.eK0;
+    P.eK1s = p.dt < 0.0 ? P.eK1 : -P.eK1;
     return P;
 }
 

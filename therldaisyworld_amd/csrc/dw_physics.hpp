@@ -160,6 +160,7 @@ struct PhysF32 {
     // exact-mode tie test (per-mille; om = 1 - beta = cbeta*((T-To)/To)^2 >= 0):
     //   |frac(gq)| > tie_lo - eA*|gq| - |dt*K|*(eK0 + eK1*om)   =>  re-evaluate in float64
     float tie_lo, eA, eK0, eK1;
+    float eK0s, eK1s;            // -sign(dt) * eK0, eK1: dK * (eK0s + eK1s*om) = -|dK| * (eK0 + eK1*om) (density >= 0)
     int hi_bits;                 // the hi parts are multiples of 2^-hi_bits (host bookkeeping)
 };
 
@@ -198,6 +199,7 @@ template <> struct Lanes<float> {
     static __device__ __forceinline__ float get(float v, int) { return v; }
     static __device__ __forceinline__ void gt(float a, float b, bool* out) { out[0] = a > b; }
     static __device__ __forceinline__ float load(const float* a, int i) { return a[i]; }
+    static __device__ __forceinline__ float fma_abs(float a, float b, float c) { return __builtin_fmaf(a, __builtin_fabsf(b), c); }
 };
 template <> struct Lanes<dw_f32x2> {
     static constexpr int N = 2;
@@ -213,6 +215,10 @@ template <> struct Lanes<dw_f32x2> {
     static __device__ __forceinline__ float get(T v, int i) { return i == 0 ? v.x : v.y; }
     static __device__ __forceinline__ void gt(T a, T b, bool* out) { out[0] = a.x > b.x; out[1] = a.y > b.y; }
     static __device__ __forceinline__ T load(const float* a, int i) { return T{a[i], a[i + 1]}; }
+    // a*|b| + c per lane with the scalar VOP3 fma: its |.| source modifier is free, packed ops have none
+    static __device__ __forceinline__ T fma_abs(float a, T b, float c) {
+        return T{__builtin_fmaf(a, __builtin_fabsf(b.x), c), __builtin_fmaf(a, __builtin_fabsf(b.y), c)};
+    }
 };
 
 template <typename T>
@@ -301,7 +307,7 @@ __device__ __forceinline__ T finish_exact_t(const PhysF32& P, T k, T gq, T dK, T
     using V = Lanes<T>;
     const T r = V::rint(gq);
     const T frac = V::abs(gq - r);                          // exact (Sterbenz)
-    const T thr = V::fma(-V::abs(dK), V::fma(T(P.eK1), om, T(P.eK0)), V::fma(T(-P.eA), V::abs(gq), T(P.tie_lo)));
+    const T thr = V::fma(dK, V::fma(T(P.eK1s), om, T(P.eK0s)), V::fma_abs(-P.eA, gq, P.tie_lo));
     V::gt(frac, thr, tie);
     return V::clip(k + r);
 }
