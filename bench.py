@@ -47,7 +47,8 @@ WORKLOADS = {
     "c2": (1024, 256, 0, "BASELINE configs[1]: 1024 worlds, 256x256, no agent, ramped luminosity"),
     "c3": (256, 1024, 1, "BASELINE configs[2]: 256 worlds, 1024x1024, 1 greedy agent per world"),
     "c5": (8, 8192, 16, "BASELINE configs[4] per-GPU shard: 8 worlds, 8192x8192, 16 mixed-policy agents"),
-    "target": (256, 4096, 0, "north-star grid: 4096x4096 worlds, no agent (worlds sized to fit beside other tenants)"),
+    "target": (1024, 4096, 0, "north-star target: 1024 worlds of 4096x4096, no agent (256 GiB of float32 ping-pong "
+                              "state in the 288 GB of one MI355X; --worlds N for a smaller ensemble)"),
     "c4": (1000, 8, 4, "BASELINE configs[3] per-GPU shard at the README's grid: 1000 worlds, 8x8, 4 greedy agents, "
                        "device-resident episode loop (dw_run_episode)"),
 }

@@ -628,7 +628,7 @@ int dw_get_params(const dw_handle* h, dw_params* out) {
 static int refresh_stats_f32(dw_handle* h) {
     const dw_params& p = h->prm;
     for (int i = 0; i < 2; ++i) HIPCHK(hipMemsetAsync(h->stats2[i], 0, h->stats_bytes, h->stream));
-    const dim3 g((unsigned)((p.height * p.width + 255) / 256), (unsigned)p.batch);
+    const dim3 g((unsigned)((p.height * p.width + kStatsChunk - 1) / kStatsChunk), (unsigned)p.batch);
     hipLaunchKernelGGL((stats_only<float>), g, dim3(256), 0, h->stream, h->L32[h->cur], h->D32[h->cur],
                        p.height, p.width, h->stats2[h->sp]);
     HIPCHK(hipGetLastError());

@@ -911,6 +911,26 @@ struct FusedGeom {
     int qcap, mcap;           // queue / mismatch-list capacities in use (tests shrink them)
 };
 
+// float64 step-1 value of grid cell (r, c) (any integers: wrapped onto the torus) from the input planes,
+// as a packed light | dark << 16 word
+__device__ inline unsigned int exact1_word(const float* __restrict__ pL, const float* __restrict__ pD, int H, int W,
+                                           int r, int c, const PhysF64& Pa) {
+    const int rr = ((r % H) + H) % H, cc = ((c % W) + W) % W;
+    const int ru = rr == 0 ? H - 1 : rr - 1, rd = rr == H - 1 ? 0 : rr + 1;
+    const int cl = cc == 0 ? W - 1 : cc - 1, cr = cc == W - 1 ? 0 : cc + 1;
+    const int rows[3] = {ru, rr, rd}, cols[3] = {cl, cc, cr};
+    unsigned int w1[9];
+#pragma unroll
+    for (int x = 0; x < 3; ++x)
+#pragma unroll
+        for (int y = 0; y < 3; ++y) {
+            const size_t o = (size_t)rows[x] * W + cols[y];
+            w1[x * 3 + y] = (unsigned)pL[o] | ((unsigned)pD[o] << 16);
+        }
+    const NewCoverF64 s1 = cell_f64_lean(Pa, w1);
+    return (unsigned)dw_round3_k(s1.nl) | ((unsigned)dw_round3_k(s1.nd) << 16);
+}
+
 // exact two-step value of one cell straight from the input planes, all in float64: nine step-1
 // evaluations (luminosity La) feeding one step-2 evaluation (Lb).  Used only to repair the rare
 // dependents of a float32 step-1 mismatch and as the overflow fallback.
@@ -1108,21 +1128,32 @@ __device__ __forceinline__ void fused2_body(const float* __restrict__ inL, const
         unsigned int nmm = 0;
         bool redo = nq > (unsigned)G.qcap;
         if (!redo) {
-            // F1: queued step-1 cells -> mismatch list
+            // F1 + F2 in one sweep over the queue (the entries differ only in the luminosity of their
+            // float64 re-evaluation): a step-1 entry whose float32 value was wrong goes to the mismatch
+            // list; a step-2 entry (payload = float32 step-1 values) patches the output - cells next to a
+            // mismatch are overwritten by F3 below.
             for (unsigned int base = 0; base < nq; base += 64) {
                 const unsigned int e = base + lane;
                 bool mism = false;
                 unsigned int where = 0;
                 if (e < nq) {
                     const uint4 e0 = q[e * 3], e1 = q[e * 3 + 1], e2 = q[e * 3 + 2];
+                    const unsigned int w[9] = {unpack_ld(e0.z), unpack_ld(e0.w), unpack_ld(e1.x),
+                                               unpack_ld(e1.y), unpack_ld(e1.z), unpack_ld(e1.w),
+                                               unpack_ld(e2.x), unpack_ld(e2.y), unpack_ld(e2.z)};
+                    PhysF64 Pe = Pa;
+                    Pe.L = e0.x == 1u ? La : Lb;
+                    const NewCoverF64 o = cell_f64_lean(Pe, w);
+                    const unsigned int kl = (unsigned)dw_round3_k(o.nl), kd = (unsigned)dw_round3_k(o.nd);
+                    where = e0.y;
                     if (e0.x == 1u) {
-                        const unsigned int w[9] = {unpack_ld(e0.z), unpack_ld(e0.w), unpack_ld(e1.x),
-                                                   unpack_ld(e1.y), unpack_ld(e1.z), unpack_ld(e1.w),
-                                                   unpack_ld(e2.x), unpack_ld(e2.y), unpack_ld(e2.z)};
-                        const NewCoverF64 o = cell_f64_lean(Pa, w);
-                        const unsigned int exact = (unsigned)dw_round3_k(o.nl) | ((unsigned)dw_round3_k(o.nd) << 16);
-                        mism = exact != unpack_ld(e2.w);
-                        where = e0.y;
+                        mism = (kl | (kd << 16)) != unpack_ld(e2.w);
+                    } else {
+                        int gr, gc;
+                        grid_rc((int)(where >> 16), (int)(where & 0xffffu), gr, gc);
+                        const size_t off = woff + (size_t)gr * G.W + gc;
+                        outL[off] = (float)kl;
+                        outD[off] = (float)kd;
                     }
                 }
                 const unsigned long long mask = __ballot(mism);
@@ -1136,36 +1167,49 @@ __device__ __forceinline__ void fused2_body(const float* __restrict__ inL, const
             redo = nmm > (unsigned)G.mcap;
         }
         if (!redo) {
-            // F2: queued step-2 cells (their payload holds float32 step-1 values; cells next to a mismatch
-            // are overwritten by F3 below)
-            for (unsigned int e = lane; e < nq; e += 64) {
-                const uint4 e0 = q[e * 3], e1 = q[e * 3 + 1], e2 = q[e * 3 + 2];
-                if (e0.x != 2u) continue;
-                const unsigned int w[9] = {unpack_ld(e0.z), unpack_ld(e0.w), unpack_ld(e1.x),
-                                           unpack_ld(e1.y), unpack_ld(e1.z), unpack_ld(e1.w),
-                                           unpack_ld(e2.x), unpack_ld(e2.y), unpack_ld(e2.z)};
-                const NewCoverF64 o = cell_f64_lean(Pb, w);
-                int gr, gc;
-                grid_rc((int)(e0.y >> 16), (int)(e0.y & 0xffffu), gr, gc);
-                const size_t off = woff + (size_t)gr * G.W + gc;
-                outL[off] = (float)dw_round3_k(o.nl);
-                outD[off] = (float)dw_round3_k(o.nd);
-            }
-            // F3: the nine dependents of every step-1 mismatch, entirely in float64 from the inputs
-            for (unsigned int pidx = lane; pidx < nmm * 9u; pidx += 64) {
-                const unsigned int m = pidx / 9u, t = pidx - m * 9u;
-                const unsigned int where = mm[m];
-                int lrow = (int)(where >> 16) + (int)(t / 3u) - 1;
-                int lc = (int)(where & 0xffffu) + (int)(t % 3u) - 1;
-                if (ROT) lc = (lc + 256) & 255;
-                if (!is_output(lrow, lc)) continue;
-                int gr, gc;
-                grid_rc(lrow, lc, gr, gc);
-                float kl, kd;
-                exact2_cell(pL, pD, G.H, G.W, gr, gc, Pa, Pb, kl, kd);
-                const size_t off = woff + (size_t)gr * G.W + gc;
-                outL[off] = kl;
-                outD[off] = kd;
+            // F3: everything that depends on a step-1 mismatch, entirely in float64 from the inputs.  Two
+            // mismatches per pass: 2 x 25 lanes evaluate step 1 on the 5x5 block around their mismatch
+            // (exchanged through the wave's - by now consumed - queue memory), then 2 x 9 lanes evaluate
+            // step 2 on the 3x3 block of dependents.  One float64 evaluation per lane and stage instead of
+            // ten in a row on nine lanes.
+            unsigned int* s1 = reinterpret_cast<unsigned int*>(q);
+            for (unsigned int m0 = 0; m0 < nmm; m0 += 2) {
+                __builtin_amdgcn_wave_barrier();
+                {
+                    const unsigned int mi = lane / 25u, t = lane - mi * 25u;
+                    if (lane < 50 && m0 + mi < nmm) {
+                        const unsigned int where = mm[m0 + mi];
+                        const int lrow = (int)(where >> 16) + (int)(t / 5u) - 2;
+                        const int lc = (int)(where & 0xffffu) + (int)(t % 5u) - 2;
+                        s1[lane] = exact1_word(pL, pD, G.H, G.W, r0 - 2 + lrow, c00 + lc, Pa);
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                {
+                    const unsigned int mi = lane / 9u, t = lane - mi * 9u;
+                    if (lane < 18 && m0 + mi < nmm) {
+                        const unsigned int where = mm[m0 + mi];
+                        const int dy = (int)(t / 3u) - 1, dx = (int)(t % 3u) - 1;
+                        const int lrow = (int)(where >> 16) + dy;
+                        int lc = (int)(where & 0xffffu) + dx;
+                        if (ROT) lc = (lc + 256) & 255;
+                        if (is_output(lrow, lc)) {
+                            unsigned int w2[9];
+#pragma unroll
+                            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                                for (int e = 0; e < 3; ++e) w2[a * 3 + e] = s1[mi * 25u + (unsigned)((1 + dy + a) * 5 + (1 + dx + e))];
+                            const NewCoverF64 o = cell_f64_lean(Pb, w2);
+                            int gr, gc;
+                            grid_rc(lrow, lc, gr, gc);
+                            const size_t off = woff + (size_t)gr * G.W + gc;
+                            outL[off] = (float)dw_round3_k(o.nl);
+                            outD[off] = (float)dw_round3_k(o.nd);
+                        }
+                    }
+                }
             }
         } else {
             // overflow fallback: every output cell of the strip, two float64 steps from the inputs
@@ -1845,18 +1889,29 @@ __global__ void permille_to_f64(const float* __restrict__ in, double* __restrict
 }
 
 // stats of an arbitrary state (used after uploads / init so that dw_reduce is always valid)
+constexpr int kStatsChunk = 4096;
 template <typename T>
 __global__ __launch_bounds__(256) void stats_only(const T* __restrict__ L, const T* __restrict__ D,
                                                   int H, int W, StatsDev* __restrict__ stats) {
+    // a workgroup reduces kStatsChunk cells of world blockIdx.y (coalesced, stride 256): three atomics per
+    // wave per 4096 cells instead of per 64 (the per-world counters are contended)
     const int b = blockIdx.y;
-    const int cell = blockIdx.x * 256 + threadIdx.x;
-    float kl = 0.f, kd = 0.f;
-    if (cell < H * W) {
-        kl = to_permille(L[(size_t)b * H * W + cell]);
-        kd = to_permille(D[(size_t)b * H * W + cell]);
+    const int n = H * W;
+    const int base = blockIdx.x * kStatsChunk;
+    float m = 0.f, sl = 0.f, sd = 0.f;
+    for (int i = threadIdx.x; i < kStatsChunk; i += 256) {
+        const int cell = base + i;
+        if (cell < n) {
+            const float kl = to_permille(L[(size_t)b * n + cell]);
+            const float kd = to_permille(D[(size_t)b * n + cell]);
+            m = fmaxf(m, fmaxf(kl, kd));
+            sl += kl;
+            sd += kd;
+        }
     }
-    const float m = wave_max(fmaxf(kl, kd));
-    const float sl = wave_sum(kl), sd = wave_sum(kd);
+    m = wave_max(m);
+    sl = wave_sum(sl);
+    sd = wave_sum(sd);
     if ((threadIdx.x & 63) == 0) {
         atomicMax(&stats[b].max_k, (unsigned int)ceilf(m));
         atomicAdd(&stats[b].sum_l, (unsigned long long)(sl + 0.5f));
