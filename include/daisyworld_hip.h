@@ -236,6 +236,16 @@ int dw_policy_mlp(dw_handle* h, const double* params, int32_t n_params, int32_t 
 int dw_policy_mlp_population(dw_handle* h, const double* params, int32_t n_members, const int32_t* world_member,
                              int32_t agent_begin, int32_t agent_end, double L_init);
 
+/* Device-side snapshot of the current state (both planes, agents, per-world reductions) and its
+ * restoration: lets an episode harness run chunks of steps ahead (dw_run_episode) and, when the episode
+ * turns out to have ended inside a chunk, replay exactly the steps the reference's loop
+ * (notebooks/greedy_longevity_abatement.ipynb cell 2:28-57: stop as soon as every world is dead) would
+ * have executed — without moving the state over PCIe.  Costs one extra copy of the two planes in HBM,
+ * allocated at the first save.  After a restore the retained "previous state" is not the predecessor of
+ * the current one until the next step. */
+int dw_snapshot_save(dw_handle* h);
+int dw_snapshot_restore(dw_handle* h);
+
 /* Device-resident lifespan harness (ref notebooks/greedy_longevity_abatement.ipynb cell 2:28-57):
  * accumulate done_at[b] += (max_k > threshold_k) and agents_done_at[b][n] += !(done) after each
  * step, on the device.  dw_lifespan_reset zeroes them. */
@@ -244,9 +254,11 @@ int dw_lifespan_accumulate(dw_handle* h, uint32_t threshold_k);
 int dw_lifespan_download(dw_handle* h, int32_t* done_at /* [B] */, int32_t* agents_done_at /* [B][N] */,
                          int32_t* n_worlds_alive);
 
-/* Device-resident episode loop for small worlds (H*W <= 4096): K consecutive
- * environment steps — policy, update_agents (ref :181-244), forward (ref :434-461), reductions — in
- * ONE launch with the worlds held in LDS, no host round trip per step.  It is the body of the
+/* Device-resident episode loop: K consecutive environment steps — policy,
+ * update_agents (ref :181-244), forward (ref :434-461), reductions — without a host round trip per
+ * step.  Small worlds (H*W <= 4096) run in ONE launch with the worlds held in LDS; larger worlds run the
+ * same K steps as back-to-back launches on the handle's stream (policy / table slice, update_agents, the
+ * streaming step kernel, flags from its reductions) with one synchronisation at the end.  It is the body of the
  * reference's lifespan harness (notebooks/greedy_longevity_abatement.ipynb cell 2:28-57) and of
  * sges.get_fitness (daisy/evo/sges.py:144-181) for scripted policies.
  *   L_schedule[K]   luminosity of each step (the caller runs the ref update_L recurrence :463-473)

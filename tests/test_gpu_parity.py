@@ -476,13 +476,42 @@ def test_device_episode_loop_leaves_env_like_host_loop(amd, precision):
         assert np.array_equal(x, y)
 
 
-def test_run_episode_matches_stepwise_engine(amd):
-    """dw_run_episode == K x (policy + dw_step): planes, agents, flags, reductions, previous state."""
+def test_lifespan_harness_on_large_worlds_uses_device_reductions(amd):
+    """Worlds above the LDS-resident limit (72x72) go through env.step per step, with the per-world
+    "biosphere dead" flag from the step kernel's reductions instead of a full-grid download: same
+    lifespans, final state and RNG stream as the notebook's loop verbatim (which reads env.grid)."""
+    from therldaisyworld_amd.harness import simulate_lifespan
+
+    def run(verbatim):
+        np.random.seed(29)
+        env = amd.RLDaisyWorld(grid_dimension=72, n_agents=3)
+        env.batch_size = 4
+        env.min_L, env.max_L, env.ramp_period = 1.1, 1.7, 48
+        agent = amd.Greedy(epsilon=0.5)
+        if verbatim:
+            d, a = O.simulate_lifespan(env, agent)              # resets the environment itself, like ours
+        else:
+            d, a = simulate_lifespan(env, agent)
+        out = (d, a, env.grid.copy(), env.agent_indices.copy(), env.agent_states.copy(), env.L, env.step_count,
+               np.random.rand())
+        env.close()
+        return out
+
+    ours, notebook = run(False), run(True)
+    assert ours[6] > 10
+    for x, y in zip(ours, notebook):
+        assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("B,H,W", [(9, 32, 32), (3, 72, 72), (2, 40, 256), (2, 66, 520)])
+def test_run_episode_matches_stepwise_engine(amd, B, H, W):
+    """dw_run_episode == K x (policy + dw_step): planes, agents, flags, reductions, previous state —
+    LDS-resident kernel (32x32) and the back-to-back-launch path of larger worlds (tiled / streaming)."""
     from therldaisyworld_amd import _ffi
-    B, G, N, K = 9, 32, 5, 11
+    N, K = 5, 11
     outs = []
     for mode in ("episode", "stepwise"):
-        eng = _engine(amd, B, G, G, N, "exact")
+        eng = _engine(amd, B, H, W, N, "exact")
         eng.init_random(77)
         L, dL = 1.0, 0.01
         eng.step(L, np.zeros((B, N, 1), dtype=int))         # quantise the state
@@ -513,6 +542,32 @@ def test_run_episode_matches_stepwise_engine(amd):
     for f in ("max_k", "sum_light_k", "sum_dark_k"):
         assert np.array_equal(a[5][f], b[5][f])
     assert np.array_equal(a[6], b[6]) and np.array_equal(a[7], b[7])
+
+
+@pytest.mark.parametrize("B,H,W,N", [(4, 16, 16, 3), (2, 64, 256, 2)])
+def test_snapshot_restore_replays_identically(amd, B, H, W, N):
+    """dw_snapshot_save / dw_snapshot_restore: after a restore the same steps give the same state
+    (planes, agents, reductions, observations), whatever ran in between."""
+    from therldaisyworld_amd import _ffi
+    eng = _engine(amd, B, H, W, N, "exact")
+    eng.init_random(5)
+    eng.step(0.9, np.zeros((B, N, 1), dtype=int))
+    with pytest.raises(_ffi.DaisyHipError):
+        eng.snapshot_restore()                               # nothing saved yet
+    eng.snapshot_save()
+    Ls = [0.95 + 0.01 * i for i in range(6)]
+
+    def run():
+        alive, ok = eng.run_episode(Ls, _ffi.POLICY_ARGMIN)
+        return (alive, ok, *eng.download_planes(), *eng.download_agents(), eng.reduce().tobytes(), eng.get_obs())
+
+    first = run()
+    eng.step_n(3, 1.2, 0.0, 0.75, 1.5)                       # wander off
+    eng.snapshot_restore()
+    second = run()
+    for x, y in zip(first, second):
+        assert np.array_equal(x, y)
+    eng.close()
 
 
 def test_c1_trajectory_via_episode_kernel_g2(amd, golden):

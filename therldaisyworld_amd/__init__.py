@@ -6,8 +6,9 @@ C ABI declared in ``include/daisyworld_hip.h``.  Importing this package does not
 an environment does (there is no CPU fallback).
 """
 from .daisy_world_rl import RLDaisyWorld  # noqa: F401
+from ._ffi import DaisyHipError  # noqa: F401
 from .engine import Engine, default_params  # noqa: F401
 from .agents.greedy import Greedy  # noqa: F401
 from .agents.mlp import MLP  # noqa: F401
 
-__all__ = ["RLDaisyWorld", "Engine", "default_params", "Greedy", "MLP"]
+__all__ = ["RLDaisyWorld", "Engine", "default_params", "Greedy", "MLP", "DaisyHipError"]

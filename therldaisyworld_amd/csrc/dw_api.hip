@@ -95,6 +95,13 @@ struct dw_handle {
     double* reward_d = nullptr;       // [B][N]
     unsigned char* done_d = nullptr;  // [B][N]
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // dw_snapshot_save / dw_snapshot_restore: device copy of the current state
+    float* snapL = nullptr;
+    float* snapD = nullptr;
+    int* snap_idx = nullptr;
+    double* snap_st = nullptr;
+    unsigned char* snap_stats = nullptr;
+    bool snap_valid = false, snap_quantised = false, snap_agents = false;
     // kernel selection
     int tcq = 0, rpt = 0;             // 0 => generic
     Geom geom{};
@@ -595,6 +602,8 @@ int dw_destroy(dw_handle* h) {
     (void)hipFree(h->L64); (void)hipFree(h->D64);
     (void)hipFree(h->idx); (void)hipFree(h->st); (void)hipFree(h->action); (void)hipFree(h->action_tmp);
     (void)hipFree(h->reward_d); (void)hipFree(h->done_d);
+    (void)hipFree(h->snapL); (void)hipFree(h->snapD); (void)hipFree(h->snap_idx); (void)hipFree(h->snap_st);
+    (void)hipFree(h->snap_stats);
     (void)hipFree(h->agents_done_at); (void)hipFree(h->done_at); (void)hipFree(h->n_alive);
     (void)hipFree(h->stats2[0]); (void)hipFree(h->stats2[1]); (void)hipFree(h->scratch); (void)hipFree(h->ep_buf); (void)hipFree(h->fixq); (void)hipFree(h->redo_tiles);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -1244,6 +1253,54 @@ static bool episode_kernel_applies(const dw_handle* h) {
            (p.precision != DW_PRECISION_EXACT || h->cur_quantised) && !std::getenv("DW_NO_EPISODE_KERNEL");
 }
 
+// dw_run_episode for worlds that do not fit LDS: the same K steps as K x (policy, dw_step) issued
+// back-to-back on the handle's stream - policy kernel or table slice -> update_agents -> step kernel ->
+// flags from the step's reductions - with no host round trip in between; one synchronisation at the end.
+static int run_episode_stepwise(dw_handle* h, int32_t nsteps, const double* L_schedule, int policy_mode,
+                                const uint8_t* use_table, const int8_t* table, uint32_t threshold_k,
+                                uint8_t* world_alive, uint8_t* agent_ok) {
+    const dw_params& p = h->prm;
+    const int N = p.n_agents, B = p.batch;
+    const size_t K = (size_t)nsteps, bn = (size_t)B * N;
+    auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+    const size_t o_tab = 0, o_wa = up(o_tab + K * bn), o_ok = up(o_wa + K * B), total = up(o_ok + K * bn) + 256;
+    if (h->ep_bytes < total) {
+        if (h->ep_buf) HIPCHK(hipFree(h->ep_buf));
+        h->ep_buf = nullptr; h->ep_bytes = 0;
+        HIPCHK(hipMalloc(&h->ep_buf, total));
+        h->ep_bytes = total;
+    }
+    if (table && bn) HIPCHK(hipMemcpyAsync(h->ep_buf + o_tab, table, K * bn, hipMemcpyHostToDevice, h->stream));
+    const int nflag = B > (int)bn ? B : (int)bn;
+    for (size_t t = 0; t < K; ++t) {
+        if (bn && policy_mode != kPolicySkipAgents) {
+            const bool from_table = policy_mode == DW_POLICY_TABLE || (use_table && use_table[t]);
+            if (from_table) {
+                hipLaunchKernelGGL(actions_from_table, dim3((unsigned)((bn + 255) / 256)), dim3(256), 0, h->stream,
+                                   reinterpret_cast<const signed char*>(h->ep_buf + o_tab + t * bn), (int)bn, h->action);
+            } else if (policy_mode == DW_POLICY_ZEROS) {
+                HIPCHK(hipMemsetAsync(h->action, 0, sizeof(int) * bn, h->stream));
+            } else {
+                hipLaunchKernelGGL(policy_greedy, dim3((unsigned)((bn + 255) / 256)), dim3(256), 0, h->stream,
+                                   h->L32[h->cur], h->D32[h->cur], h->idx, B, N, p.height, p.width, p.obs_mask,
+                                   policy_mode == DW_POLICY_ARGMIN ? 1 : 0, (const int*)nullptr, h->action);
+            }
+            HIPCHK(hipGetLastError());
+            int rc = launch_agents(h, h->action, B, N);
+            if (rc) return rc;
+        }
+        int rc = launch_forward(h, L_schedule[t]);
+        if (rc) return rc;
+        hipLaunchKernelGGL(episode_flags, dim3((unsigned)((nflag + 255) / 256)), dim3(256), 0, h->stream,
+                           h->stats2[h->sp], h->st, B, N, threshold_k, h->ep_buf + o_wa + t * B, h->ep_buf + o_ok + t * bn);
+        HIPCHK(hipGetLastError());
+    }
+    if (world_alive) HIPCHK(hipMemcpyAsync(world_alive, h->ep_buf + o_wa, K * B, hipMemcpyDeviceToHost, h->stream));
+    if (agent_ok && bn) HIPCHK(hipMemcpyAsync(agent_ok, h->ep_buf + o_ok, K * bn, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return DW_OK;
+}
+
 static int run_episode_impl(dw_handle* h, int32_t nsteps, const double* L_schedule, int policy_mode,
                             const uint8_t* use_table, const int8_t* table, uint32_t threshold_k,
                             uint8_t* world_alive, uint8_t* agent_ok) {
@@ -1253,7 +1310,6 @@ static int run_episode_impl(dw_handle* h, int32_t nsteps, const double* L_schedu
     NEED(p.precision != DW_PRECISION_F64, DW_EINVAL, "dw_run_episode supports exact and fast precision");
     NEED(p.collision_mode == 0, DW_EINVAL, "collision_mode=1 is not implemented on the device");
     const int C = p.height * p.width, N = p.n_agents, B = p.batch;
-    NEED(C <= 4096, DW_EINVAL, "dw_run_episode is for small worlds (H*W <= 4096); use dw_step_n / dw_step");
     NEED(h->have_state, DW_ESTATE, "no state uploaded");
     NEED(N == 0 || h->have_agents, DW_ESTATE, "no agents uploaded");
     NEED(p.precision != DW_PRECISION_EXACT || h->cur_quantised, DW_ESTATE,
@@ -1261,6 +1317,9 @@ static int run_episode_impl(dw_handle* h, int32_t nsteps, const double* L_schedu
     NEED(policy_mode != DW_POLICY_TABLE || table, DW_EINVAL, "DW_POLICY_TABLE needs a table");
     if (use_table && !table)
         for (int t = 0; t < nsteps; ++t) NEED(!use_table[t], DW_EINVAL, "use_table set but no table given");
+    if (C > 4096 || std::getenv("DW_NO_EPISODE_KERNEL"))
+        return run_episode_stepwise(h, nsteps, L_schedule, policy_mode, use_table, table, threshold_k, world_alive,
+                                    agent_ok);
     const int wpb = C <= 256 ? 4 : (C <= 1024 ? 2 : 1);
     const size_t world_bytes = ((size_t)16 * C + (size_t)N * 8 + (size_t)N * 12 + 16 + 15) / 16 * 16;
     const size_t lds = world_bytes * wpb;
@@ -1313,6 +1372,56 @@ static int run_episode_impl(dw_handle* h, int32_t nsteps, const double* L_schedu
     h->stepped = true;
     h->L_last = L_schedule[K - 1];
     HIPCHK(hipStreamSynchronize(h->stream));      // host vectors above go out of scope; flags are returned
+    return DW_OK;
+}
+
+// ---- device-side snapshot of the current state ----------------------------------------------------
+int dw_snapshot_save(dw_handle* h) {
+    NEED(h, DW_EINVAL, "null handle");
+    const dw_params& p = h->prm;
+    HIPCHK(hipSetDevice(p.device));
+    NEED(h->have_state, DW_ESTATE, "no state uploaded");
+    NEED(h->f64 != F64_CUR, DW_ESTATE, "the current state is an un-quantised float64 upload; take a step first");
+    const size_t bn = (size_t)p.batch * p.n_agents;
+    if (!h->snapL) {
+        HIPCHK(hipMalloc(&h->snapL, sizeof(float) * h->cells));
+        HIPCHK(hipMalloc(&h->snapD, sizeof(float) * h->cells));
+        HIPCHK(hipMalloc(&h->snap_stats, h->stats_bytes));
+        if (bn) {
+            HIPCHK(hipMalloc(&h->snap_idx, sizeof(int) * 2 * bn));
+            HIPCHK(hipMalloc(&h->snap_st, sizeof(double) * bn));
+        }
+    }
+    HIPCHK(hipMemcpyAsync(h->snapL, h->L32[h->cur], sizeof(float) * h->cells, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->snapD, h->D32[h->cur], sizeof(float) * h->cells, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->snap_stats, h->stats2[h->sp], h->stats_bytes, hipMemcpyDeviceToDevice, h->stream));
+    h->snap_agents = bn && h->have_agents;
+    if (h->snap_agents) {
+        HIPCHK(hipMemcpyAsync(h->snap_idx, h->idx, sizeof(int) * 2 * bn, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->snap_st, h->st, sizeof(double) * bn, hipMemcpyDeviceToDevice, h->stream));
+    }
+    h->snap_quantised = h->cur_quantised;
+    h->snap_valid = true;
+    return DW_OK;
+}
+
+int dw_snapshot_restore(dw_handle* h) {
+    NEED(h, DW_EINVAL, "null handle");
+    const dw_params& p = h->prm;
+    HIPCHK(hipSetDevice(p.device));
+    NEED(h->snap_valid, DW_ESTATE, "no snapshot saved");
+    const size_t bn = (size_t)p.batch * p.n_agents;
+    HIPCHK(hipMemcpyAsync(h->L32[h->cur], h->snapL, sizeof(float) * h->cells, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->D32[h->cur], h->snapD, sizeof(float) * h->cells, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->stats2[h->sp], h->snap_stats, h->stats_bytes, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(hipMemsetAsync(h->stats2[1 - h->sp], 0, h->stats_bytes, h->stream));
+    if (h->snap_agents) {
+        HIPCHK(hipMemcpyAsync(h->idx, h->snap_idx, sizeof(int) * 2 * bn, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->st, h->snap_st, sizeof(double) * bn, hipMemcpyDeviceToDevice, h->stream));
+    }
+    h->f64 = F64_NONE;
+    h->cur_quantised = h->snap_quantised;
+    h->stepped = false;                         // the other buffer is no longer this state's predecessor
     return DW_OK;
 }
 

@@ -1816,6 +1816,24 @@ __global__ __launch_bounds__(256) void tie_audit(const float* __restrict__ L, co
     atomicAdd(&out[3], 2ull);
 }
 
+// dw_run_episode on worlds that do not fit LDS: one step's flags from the step kernel's reductions
+// (same predicates as episode_small), and one step's actions out of the caller's int8 table
+__global__ void episode_flags(const StatsDev* __restrict__ stats, const double* __restrict__ st, int B, int N,
+                              unsigned int thr, unsigned char* __restrict__ world_alive,
+                              unsigned char* __restrict__ agent_ok) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B) world_alive[i] = stats[i].max_k > thr ? 1 : 0;
+    if (i < B * N) {
+        const double s = st[i];
+        const double rw = s * (s > 0.0 ? 1.0 : 0.0);
+        agent_ok[i] = rw < 0.1 ? 0 : 1;
+    }
+}
+__global__ void actions_from_table(const signed char* __restrict__ table, int n, int* __restrict__ action) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) action[i] = (int)table[i];
+}
+
 // lifespan counters (ref notebooks/greedy_longevity_abatement.ipynb cell 2:46-52)
 __global__ void lifespan_accumulate(const StatsDev* __restrict__ stats, const double* __restrict__ st,
                                     int B, int N, unsigned int thr, int* __restrict__ done_at,

@@ -230,8 +230,16 @@ class Engine:
                                              C.byref(alive)))
         return done_at, agents, alive.value
 
+    def snapshot_save(self):
+        """Device-side copy of the current state (planes, agents, reductions)."""
+        check(self._lib.dw_snapshot_save(self._h))
+
+    def snapshot_restore(self):
+        check(self._lib.dw_snapshot_restore(self._h))
+
     def run_episode(self, L_schedule, policy_mode, use_table=None, table=None, threshold_k=5):
-        """K device-resident steps (small worlds).  Returns (world_alive (K,B) bool, agent_ok (K,B,N) bool)."""
+        """K device-resident steps (one launch for H*W <= 4096, back-to-back launches otherwise).
+        Returns (world_alive (K,B) bool, agent_ok (K,B,N) bool)."""
         Ls = np.ascontiguousarray(L_schedule, dtype=np.float64)
         K = Ls.shape[0]
         ut = None if use_table is None else np.ascontiguousarray(use_table, dtype=np.uint8)

@@ -6,12 +6,14 @@ biosphere is dead and return, per world, the number of steps it was alive and, p
 steps its reward stayed >= 0.1.  Results and legacy-NumPy-RNG consumption are identical to running the
 notebook's loop on the reference.
 
-For small worlds (H*W <= 4096, scripted policy) the loop does not call ``env.step`` per step: whole chunks
-of steps run device-resident (``dw_run_episode``: policy, grazing, physics and the per-step alive flags in
-one launch with the worlds in LDS); the host only draws the policy's random numbers for the chunk in the
+For scripted policies (``Greedy`` in any of its modes, or no agent) the loop does not call ``env.step`` per
+step: whole chunks of steps run device-resident (``dw_run_episode``: policy, grazing, physics and the
+per-step alive flags — one launch with the worlds in LDS for H*W <= 4096, back-to-back launches without
+host round trips for larger worlds); the host only draws the policy's random numbers for the chunk in the
 reference's order and post-processes the flags.  If the episode ends inside a chunk the chunk is replayed
-from a snapshot for exactly the remaining steps, so the environment is left in the very state (grid, agents,
-L, step_count, RNG stream) the reference loop would leave it in.
+from a device-side snapshot (``dw_snapshot_save/restore``) for exactly the remaining steps, so the
+environment is left in the very state (grid, agents, L, step_count, RNG stream) the reference loop would
+leave it in.
 """
 from __future__ import annotations
 
@@ -23,12 +25,23 @@ from .agents.greedy import Greedy
 LIFESPAN_THRESHOLD_K = 5          # grid_done = max cover <= 0.005 (notebook cell 2:48)
 
 
+def _grid_done(env):
+    """ref notebook cell 2:48: `env.grid[:, 1:3].max(axis=(1, 2, 3)) <= 0.005` per world.  On the drop-in
+    environment the per-world maximum is a by-product of the step kernel (per-mille integer, `dw_reduce`):
+    k <= 5 is the same predicate without materialising and downloading the 7-channel float64 grid
+    (3.7 GB per step for 1000 worlds of 256x256)."""
+    from .daisy_world_rl import RLDaisyWorld
+    if isinstance(env, RLDaisyWorld) and (env._grid_m is None or not env._grid_m.dirty()):
+        return env._engine.reduce()["max_k"] <= LIFESPAN_THRESHOLD_K
+    return env.grid[:, 1:3, :, :].max(axis=(1, 2, 3)) <= 0.005
+
+
 def _simulate_on_host(env, agent, obs, done_at, agents_done_at):
-    """The notebook's loop verbatim (any environment / any callable agent)."""
+    """The notebook's loop (any environment / any callable agent), one `env.step` per step."""
     while True:
         action = agent(obs) if agent is not None else None
         obs, reward, done, info = env.step(action)
-        grid_done = env.grid[:, 1:3, :, :].max(axis=(1, 2, 3)) <= 0.005
+        grid_done = _grid_done(env)
         done_at += (1 - 1 * grid_done)
         agents_done_at += (1 - 1 * done)
         if grid_done.mean() == 1.0:
@@ -59,14 +72,18 @@ def _luminosity_schedule(env, nsteps):
     return out
 
 
-def simulate_lifespan(env, agent, chunk=32, use_device_loop=True):
-    obs = env.reset()
+def simulate_lifespan(env, agent, chunk=32, use_device_loop=True, obs=None):
+    """`obs=None`: reset the environment first, as the notebook's harness does.  Pass the observations of
+    a reset the caller has already done (e.g. `env.reset_synthetic(seed); obs = env.get_obs()` — the
+    device-side initial state for ensembles too large to draw from the host's legacy RNG)."""
+    if obs is None:
+        obs = env.reset()
     B, N = obs.shape[0], obs.shape[1]
     done_at = np.zeros((B,), dtype=int)
     agents_done_at = np.zeros((B, N, 1), dtype=int)
     mode = _policy_mode(agent)
-    small = env.dim * env.dim <= 4096 and env.precision != "f64" and env.collision_mode == 0
-    if not (use_device_loop and small and mode is not None):
+    supported = env.precision != "f64" and env.collision_mode == 0
+    if not (use_device_loop and supported and mode is not None):
         return _simulate_on_host(env, agent, obs, done_at, agents_done_at)
 
     eng = env._engine
@@ -90,7 +107,7 @@ def simulate_lifespan(env, agent, chunk=32, use_device_loop=True):
                 table[t] = agent.draw_random_actions(B, N)[..., 0]
             rng_after.append(np.random.get_state())
         Ls = _luminosity_schedule(env, K)
-        snap = (eng.download_planes(), eng.download_agents())
+        eng.snapshot_save()
         alive_k, ok_k = eng.run_episode(Ls, mode, use_table, table, LIFESPAN_THRESHOLD_K)
         all_dead = ~alive_k.any(axis=1)
         executed = int(np.argmax(all_dead)) + 1 if all_dead.any() else K
@@ -98,9 +115,7 @@ def simulate_lifespan(env, agent, chunk=32, use_device_loop=True):
         agents_done_at += ok_k[:executed].sum(axis=0)[..., None]
         if executed < K:
             # the episode ended inside the chunk: replay exactly `executed` steps from the snapshot
-            (light, dark), (idx, st) = snap
-            eng.upload_state_f32(light.astype(np.float32), dark.astype(np.float32), quantised=True)
-            eng.upload_agents(idx, st)
+            eng.snapshot_restore()
             eng.run_episode(Ls[:executed], mode, use_table[:executed], table[:executed], LIFESPAN_THRESHOLD_K)
             np.random.set_state(rng_after[executed - 1])
         for _ in range(executed):                          # host scalars of the environment
