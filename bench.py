@@ -114,9 +114,10 @@ def cpu_baseline(grid: int, params_obj, budget_s: float = 12.0):
     }
 
 
-def load_traffic(workload: str, precision: str):
-    """HBM bytes per launch from the PMC profile of the same command, if one has been committed
-    under profiles/ (collected per the guide: separate --pmc passes, FETCH_SIZE x2 on gfx950)."""
+def load_traffic(workload: str, precision: str, steps_per_launch: int = 0):
+    """HBM bytes per launch of the dominant kernel from the PMC profile of the same command, if one has
+    been committed under profiles/ (collected per the guide: separate --pmc passes, FETCH_SIZE x2 on
+    gfx950).  `steps_per_launch` (when given) must match the profile's."""
     best = None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_*.json"))):
         try:
@@ -124,6 +125,11 @@ def load_traffic(workload: str, precision: str):
         except Exception:
             continue
         if d.get("workload") == workload and d.get("precision") == precision:
+            if steps_per_launch and d.get("steps_per_launch", 1) != steps_per_launch:
+                part = d.get("single" if steps_per_launch == 1 else "fused")
+                if not part:
+                    continue
+                d = dict(d, hbm_bytes_per_launch=part["hbm_bytes_per_launch"])
             best = d
     return None if best is None else best.get("hbm_bytes_per_launch")
 
@@ -221,9 +227,12 @@ def main():
         kernel_ms = ev_ms / steps
         achieved = BYTES_PER_CELL_UPDATE * cells / (kernel_ms * 1e-3) / 1e9
         stats = eng.reduce()
+        info = eng.kernel_info()
+        # dw_step_n runs wide agent-free grids as fused step PAIRS: the dominant kernel's launch = 2 steps
+        spl = 2 if (N == 0 and "fuses step pairs" in info and not os.environ.get("DW_NO_FUSE")) else 1
         res = {"value": cells * steps * n_gpus / elapsed, "ms_per_step": elapsed / steps * 1e3,
                "kernel_ms": kernel_ms, "achieved": achieved, "frac": achieved / HBM_PEAK_GBS,
-               "fixups": eng.last_fixup_count(), "kernel": eng.kernel_info(), "stats": stats}
+               "fixups": eng.last_fixup_count(), "kernel": info, "stats": stats, "steps_per_launch": spl}
         eng.close()
         return res
 
@@ -250,10 +259,20 @@ def main():
         "config": {"workload": f"{args.workload}: {desc}", "worlds_per_gpu": B, "grid": [G, G], "agents_per_world": N,
                    "precision": args.precision, "kernel": info, "total_worlds": int(all_stats.shape[0]),
                    "parallelism": f"ensemble shard x{n_gpus} (no data-path collective)"},
+        # per launch of the dominant kernel: algorithmic bytes = 16 B x cell-updates of one launch; achieved =
+        # that / the launch duration (HIP events on the kernel's stream / launches); traffic = PMC HBM bytes
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(args.workload, args.precision),
-                     "bytes_per_cell_update": BYTES_PER_CELL_UPDATE, "cells_per_launch": cells,
-                     "kernel_ms": kernel_ms, "f64_fixups_last_step": fixups},
+                     "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": load_traffic(args.workload, args.precision, m["steps_per_launch"]),
+                     "bytes_per_cell_update": BYTES_PER_CELL_UPDATE, "steps_per_launch": m["steps_per_launch"],
+                     "cell_updates_per_launch": cells * m["steps_per_launch"],
+                     "algorithmic_bytes_per_launch": BYTES_PER_CELL_UPDATE * cells * m["steps_per_launch"],
+                     "launch_ms": kernel_ms * m["steps_per_launch"], "kernel_ms_per_step": kernel_ms,
+                     "f64_fixups_last_step": fixups,
+                     "note": ("two steps share one HBM round trip (temporal blocking in registers): measured traffic "
+                              "is about half the algorithmic bytes, so frac may exceed 1; the fused kernels are "
+                              "VALU-issue-bound (72-74 % busy, profiles/r01e_valu_pmc.json)")
+                     if m["steps_per_launch"] == 2 else "single-step kernel: HBM-bound"},
     }
     if not args.no_modes:
         # the other arithmetic mode on the same workload, for the record (shorter run).  In "fast" mode
@@ -263,7 +282,8 @@ def main():
         o = measure(other, max(10, args.steps // 2), max(4, args.warmup // 2))
         out["modes"] = {other: {"value": o["value"], "ms_per_step": o["ms_per_step"], "kernel_ms": o["kernel_ms"],
                                 "achieved_GBps": o["achieved"], "frac": o["frac"], "kernel": o["kernel"],
-                                "traffic": load_traffic(args.workload, other)}}
+                                "steps_per_launch": o["steps_per_launch"],
+                                "traffic": load_traffic(args.workload, other, o["steps_per_launch"])}}
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(G, None)
     elif rank == 0:
