@@ -662,6 +662,26 @@ def test_fused_exact_trajectory_bit_exact_vs_oracle(amd, B, H, W):
     eng.close()
 
 
+@pytest.mark.parametrize("over", [
+    dict(albedo_light=0.5, albedo_dark=0.5), dict(q2=0.0), dict(dt=0.5),
+    dict(dt=2.0, albedo_light=0.8, albedo_dark=0.2), dict(gamma=0.3, temp_optimal=290.0, g=0.004)])
+@pytest.mark.parametrize("B,H,W", [(2, 64, 256), (1, 40, 264)])
+def test_fused_exact_other_constants_vs_oracle(amd, over, B, H, W):
+    """Fused exact step pairs with the constants callers change (neutral albedo, no microclimate, dt,
+    growth parameters): both steps of a launch share their luminosity-independent coefficients and use
+    one hi/lo split scale — still bit-identical to the float64 oracle over a luminosity ramp."""
+    eng = _engine(amd, B, H, W, 0, "exact", **over)
+    assert "step_stream_fused2_exact" in eng.kernel_info()
+    eng.init_random(3)
+    light, dark = eng.download_planes()
+    Lg = eng.step_n(31, 0.8, 0.02, 0.75, 1.5)
+    Lo = c_oracle.step_n(light, dark, 0.8, 0.02, 31, params=_oracle_params(**over))
+    gl, gd = eng.download_planes()
+    assert Lg == Lo
+    assert np.array_equal(_k(gl), _k(light)) and np.array_equal(_k(gd), _k(dark))
+    eng.close()
+
+
 @pytest.mark.parametrize("B,H,W,nsteps", [(2, 256, 256, 7), (1, 70, 320, 6), (2, 64, 128, 3)])
 @pytest.mark.parametrize("qcap,mcap", [(2, 64), (256, 0), (0, 0)])
 def test_exact_mode_overflow_fallbacks_are_exact(amd, monkeypatch, B, H, W, nsteps, qcap, mcap):
