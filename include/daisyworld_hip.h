@@ -236,6 +236,18 @@ int dw_policy_mlp(dw_handle* h, const double* params, int32_t n_params, int32_t 
 int dw_policy_mlp_population(dw_handle* h, const double* params, int32_t n_members, const int32_t* world_member,
                              int32_t agent_begin, int32_t agent_end, double L_init);
 
+/* Device-resident fitness episode of an evolution strategy (ref SimpleGaussianES.get_fitness,
+ * daisy/evo/sges.py:144-181, and the population loop :314-349): K consecutive steps in which agents
+ * [0, split) of world b act with MLP parameter set member_a[b] and agents [split, N) with member_b[b]
+ * (ref: `agent` drives the first half, `adversary` the second, :165-168).  Parameters and member maps go
+ * to the device once; per step: observations (ref get_obs :246-263), MLP.get_action (agents/mlp.py:97-116),
+ * update_agents, forward; the step's reward = state * (state > 0) and done = reward < 0.1 (ref :486-492)
+ * come back as [K][B][N].  member_a / member_b may be NULL when n_members == 1.  L_init: luminosity of the
+ * observations' temperature channels if no step has been taken yet. */
+int dw_run_episode_mlp(dw_handle* h, int32_t nsteps, const double* L_schedule, const double* params /* [n_members][1808] */,
+                       int32_t n_members, const int32_t* member_a /* [B] */, const int32_t* member_b /* [B] */,
+                       int32_t split, double L_init, double* reward /* [K][B][N] */, uint8_t* done /* [K][B][N] */);
+
 /* Device-side snapshot of the current state (both planes, agents, per-world reductions) and its
  * restoration: lets an episode harness run chunks of steps ahead (dw_run_episode) and, when the episode
  * turns out to have ended inside a chunk, replay exactly the steps the reference's loop

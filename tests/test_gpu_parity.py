@@ -757,6 +757,32 @@ def test_get_fitness_harness_matches_reference_rollout_g10(amd, golden):
     env.close(); env2.close()
 
 
+@pytest.mark.parametrize("chunk", [64, 7])
+def test_get_fitness_early_stop_inside_a_chunk(amd, chunk):
+    """Agents that never graze (all-zero network: action 0) starve after ~19 steps, so the episode ends
+    inside a device-resident chunk: fitness, counters and the state the environment is left in equal the
+    step-by-step loop's (chunk=1), whatever the chunk size."""
+    from therldaisyworld_amd.harness import get_fitness
+
+    def run(chunk):
+        lazy, other = amd.MLP(), amd.MLP()
+        lazy.set_parameters(np.zeros(1808))
+        other.set_parameters(np.zeros(1808))
+        np.random.seed(31)
+        env = amd.RLDaisyWorld(grid_dimension=16, n_agents=4)
+        env.batch_size = 5
+        f, total, done_at = get_fitness(env, lazy, other, max_steps=100, chunk=chunk)
+        out = (f, np.asarray(total), np.asarray(done_at), env.grid.copy(), env.agent_indices.copy(),
+               env.agent_states.copy(), env.L, env.step_count)
+        env.close()
+        return out
+
+    ours, stepwise = run(chunk), run(1)
+    assert 10 < ours[7] < 40                                 # all agents done long before max_steps
+    for x, y in zip(ours, stepwise):
+        assert np.array_equal(x, y)
+
+
 def test_trained_mlp_rollout_on_device_matches_reference_fixture_g11(amd, golden):
     """The trained policy the reference ships (results/cmaes_exp_002, generation 127) on the default
     16x16 world: policy_mlp on the device + step_device_actions for 160 steps reproduce the reference's

@@ -85,6 +85,7 @@ SIGNATURES = {
     "dw_lifespan_reset": (C.c_int, [_vp]),
     "dw_lifespan_accumulate": (C.c_int, [_vp, _u32]),
     "dw_lifespan_download": (C.c_int, [_vp, _pi, _pi, _pi]),
+    "dw_run_episode_mlp": (C.c_int, [_vp, _i32, _pd, _pd, _i32, _pi, _pi, _i32, _dbl, _pd, _pu8]),
     "dw_run_episode": (C.c_int, [_vp, _i32, _pd, C.c_int, _pu8, C.POINTER(C.c_int8), _u32, _pu8, _pu8]),
     "dw_set_stream": (C.c_int, [_vp, _vp]),
     "dw_sync": (C.c_int, [_vp]),

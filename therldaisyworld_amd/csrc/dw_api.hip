@@ -1180,7 +1180,7 @@ static int policy_mlp_impl(dw_handle* h, const double* params, int32_t n_members
     HIPCHK(hipMemcpyAsync(d_w, params, wbytes, hipMemcpyHostToDevice, h->stream));
     if (world_member) HIPCHK(hipMemcpyAsync(d_m, world_member, mbytes, hipMemcpyHostToDevice, h->stream));
     const int n = p.batch * (agent_end - agent_begin);
-    hipLaunchKernelGGL(policy_mlp, dim3((n + 63) / 64), dim3(64), 0, h->stream, h->scratch, d_w, d_m, p.batch,
+    hipLaunchKernelGGL(policy_mlp, dim3((n + 3) / 4), dim3(64), 0, h->stream, h->scratch, d_w, d_m, p.batch,
                        p.n_agents, agent_begin, agent_end, h->action);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->stream));       // params / world_member are caller-owned host buffers
@@ -1201,6 +1201,70 @@ int dw_policy_mlp_population(dw_handle* h, const double* params, int32_t n_membe
     HIPCHK(hipSetDevice(h->prm.device));
     NEED(n_members >= 1, DW_EINVAL, "n_members < 1");
     return policy_mlp_impl(h, params, n_members, world_member, agent_begin, agent_end, L_init);
+}
+
+// K steps with MLP policies without a host round trip: parameters and member maps go to the device once;
+// per step: observe (all agents) -> policy_mlp for [0, split) and [split, N) -> update_agents -> step ->
+// reward / done of the step into the [K][B][N] device buffers; one download and synchronisation at the end.
+int dw_run_episode_mlp(dw_handle* h, int32_t nsteps, const double* L_schedule, const double* params, int32_t n_members,
+                       const int32_t* member_a, const int32_t* member_b, int32_t split, double L_init, double* reward,
+                       uint8_t* done) {
+    NEED(h && L_schedule && params, DW_EINVAL, "null argument");
+    const dw_params& p = h->prm;
+    HIPCHK(hipSetDevice(p.device));
+    NEED(nsteps >= 1 && nsteps <= 4096, DW_EINVAL, "nsteps must be in 1..4096");
+    NEED(n_members >= 1, DW_EINVAL, "n_members < 1");
+    NEED(p.collision_mode == 0, DW_EINVAL, "collision_mode=1 is not implemented on the device");
+    NEED(split >= 0 && split <= p.n_agents, DW_EINVAL, "split outside 0..n_agents");
+    NEED(h->have_state && h->have_agents, DW_ESTATE, "no state / agents");
+    const int B = p.batch, N = p.n_agents;
+    const size_t K = (size_t)nsteps, bn = (size_t)B * N;
+    NEED(bn > 0, DW_EINVAL, "no agents");
+    for (int b = 0; b < B; ++b) {
+        NEED(!member_a || (member_a[b] >= 0 && member_a[b] < n_members), DW_EINVAL, "world %d: member out of range", b);
+        NEED(!member_b || (member_b[b] >= 0 && member_b[b] < n_members), DW_EINVAL, "world %d: member out of range", b);
+    }
+    NEED(n_members == 1 || (member_a && member_b), DW_EINVAL, "several parameter sets need both member maps");
+    auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+    const size_t wbytes = sizeof(double) * 1808 * (size_t)n_members;
+    const size_t o_w = 0, o_ma = up(o_w + wbytes), o_mb = up(o_ma + sizeof(int) * B), o_r = up(o_mb + sizeof(int) * B);
+    const size_t o_d = up(o_r + sizeof(double) * K * bn), total = up(o_d + K * bn);
+    if (h->ep_bytes < total) {
+        if (h->ep_buf) HIPCHK(hipFree(h->ep_buf));
+        h->ep_buf = nullptr; h->ep_bytes = 0;
+        HIPCHK(hipMalloc(&h->ep_buf, total));
+        h->ep_bytes = total;
+    }
+    const double* d_w = reinterpret_cast<const double*>(h->ep_buf + o_w);
+    const int* d_ma = member_a ? reinterpret_cast<const int*>(h->ep_buf + o_ma) : nullptr;
+    const int* d_mb = member_b ? reinterpret_cast<const int*>(h->ep_buf + o_mb) : nullptr;
+    double* d_r = reinterpret_cast<double*>(h->ep_buf + o_r);
+    unsigned char* d_d = h->ep_buf + o_d;
+    HIPCHK(hipMemcpyAsync(h->ep_buf + o_w, params, wbytes, hipMemcpyHostToDevice, h->stream));
+    if (member_a) HIPCHK(hipMemcpyAsync(h->ep_buf + o_ma, member_a, sizeof(int) * B, hipMemcpyHostToDevice, h->stream));
+    if (member_b) HIPCHK(hipMemcpyAsync(h->ep_buf + o_mb, member_b, sizeof(int) * B, hipMemcpyHostToDevice, h->stream));
+    for (size_t t = 0; t < K; ++t) {
+        int rc = observe_into_scratch(h, L_init, 0);
+        if (rc) return rc;
+        if (split > 0)
+            hipLaunchKernelGGL(policy_mlp, dim3((unsigned)((B * split + 3) / 4)), dim3(64), 0, h->stream, h->scratch, d_w,
+                               d_ma, B, N, 0, split, h->action);
+        if (split < N)
+            hipLaunchKernelGGL(policy_mlp, dim3((unsigned)((B * (N - split) + 3) / 4)), dim3(64), 0, h->stream, h->scratch,
+                               d_w, d_mb, B, N, split, N, h->action);
+        HIPCHK(hipGetLastError());
+        rc = launch_agents(h, h->action, B, N);
+        if (rc) return rc;
+        rc = launch_forward(h, L_schedule[t]);
+        if (rc) return rc;
+        hipLaunchKernelGGL(reward_done, dim3((unsigned)((bn + 255) / 256)), dim3(256), 0, h->stream, h->st, d_r + t * bn,
+                           d_d + t * bn, (int)bn);
+        HIPCHK(hipGetLastError());
+    }
+    if (reward) HIPCHK(hipMemcpyAsync(reward, d_r, sizeof(double) * K * bn, hipMemcpyDeviceToHost, h->stream));
+    if (done) HIPCHK(hipMemcpyAsync(done, d_d, K * bn, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return DW_OK;
 }
 
 int dw_lifespan_reset(dw_handle* h) {

@@ -1714,53 +1714,63 @@ __global__ void policy_greedy(const float* __restrict__ cL, const float* __restr
 // ---------------------------------------------------------------------------------------------
 // policy_mlp — ref MLP.get_action (daisy/agents/mlp.py:97-116): 63 -> 16 -> 32 -> 9 ReLU network on
 // the flattened (7,3,3) observation, action = argmax of the logits (first maximum).  float64 like the
-// reference.  One thread per (world, agent) for agents [a0, a1) of every world; `obs` is the
+// reference.  Agents [a0, a1) of every world; `obs` is the
 // [B][N][63] buffer written by `observe`, `W` the flat parameter vector (three matrices raveled
 // row-major in layer order, ref get_parameters :118-125).  SURVEY.md §8(f) row N3.
 // ---------------------------------------------------------------------------------------------
 // `member` (optional): parameter set of each world — a whole ES population evaluated as one ensemble
 // (world b uses W + member[b] * 1808); nullptr = one set for all worlds.
-__global__ void policy_mlp(const double* __restrict__ obs, const double* __restrict__ W, const int* __restrict__ member,
-                           int B, int N, int a0, int a1, int* __restrict__ action) {
+// Sixteen lanes per agent (four agents per wave): lane j owns hidden unit j of layer 1, units j and j+16
+// of layer 2 and logit j (< 9); every dot product is accumulated sequentially in index order with fma,
+// activations travel through LDS.  ~130 dependent float64 fmas per agent instead of 1808 in one thread.
+__global__ __launch_bounds__(64) void policy_mlp(const double* __restrict__ obs, const double* __restrict__ W,
+                                                 const int* __restrict__ member, int B, int N, int a0, int a1,
+                                                 int* __restrict__ action) {
+    __shared__ double s_x[4][64], s_h1[4][16], s_h2[4][32], s_o[4][16];
     const int na = a1 - a0;
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= B * na) return;
-    const int b = t / na, n = a0 + (t - b * na);
+    const int g = threadIdx.x >> 4, j = threadIdx.x & 15;
+    const int t = blockIdx.x * 4 + g;                       // agent handled by this 16-lane group
+    const bool valid = t < B * na;
+    const int tc = valid ? t : 0;
+    const int b = tc / na, n = a0 + (tc - b * na);
     const double* x = obs + ((size_t)b * N + n) * 63;
     if (member) W += (size_t)member[b] * 1808;
     const double* W1 = W;                 // [63][16]
     const double* W2 = W + 63 * 16;       // [16][32]
     const double* W3 = W2 + 16 * 32;      // [32][9]
-    double h1[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) h1[j] = 0.0;
-    for (int i = 0; i < 63; ++i) {
-        const double xi = x[i];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) h1[j] += xi * W1[i * 16 + j];
-    }
-#pragma unroll
-    for (int j = 0; j < 16; ++j) h1[j] = h1[j] * (h1[j] > 0.0 ? 1.0 : 0.0);
-    double h2[32];
-#pragma unroll
-    for (int j = 0; j < 32; ++j) h2[j] = 0.0;
+    for (int i = j; i < 63; i += 16) s_x[g][i] = x[i];
+    __syncthreads();
+    double h = 0.0;
+    for (int i = 0; i < 63; ++i) h = __builtin_fma(s_x[g][i], W1[i * 16 + j], h);
+    s_h1[g][j] = h * (h > 0.0 ? 1.0 : 0.0);
+    __syncthreads();
+    double u = 0.0, v = 0.0;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-#pragma unroll
-        for (int j = 0; j < 32; ++j) h2[j] += h1[i] * W2[i * 32 + j];
+        const double hi = s_h1[g][i];
+        u = __builtin_fma(hi, W2[i * 32 + j], u);
+        v = __builtin_fma(hi, W2[i * 32 + j + 16], v);
     }
+    s_h2[g][j] = u * (u > 0.0 ? 1.0 : 0.0);
+    s_h2[g][j + 16] = v * (v > 0.0 ? 1.0 : 0.0);
+    __syncthreads();
+    if (j < 9) {
+        double o = 0.0;
 #pragma unroll
-    for (int j = 0; j < 32; ++j) h2[j] = h2[j] * (h2[j] > 0.0 ? 1.0 : 0.0);
-    int best = 0;
-    double bestv = 0.0;
-#pragma unroll
-    for (int j = 0; j < 9; ++j) {
-        double v = 0.0;
-#pragma unroll
-        for (int i = 0; i < 32; ++i) v += h2[i] * W3[i * 9 + j];
-        if (j == 0 || v > bestv) { best = j; bestv = v; }
+        for (int i = 0; i < 32; ++i) o = __builtin_fma(s_h2[g][i], W3[i * 9 + j], o);
+        s_o[g][j] = o;
     }
-    action[(size_t)b * N + n] = best;
+    __syncthreads();
+    if (j == 0 && valid) {
+        int best = 0;
+        double bestv = s_o[g][0];
+#pragma unroll
+        for (int k = 1; k < 9; ++k) {
+            const double o = s_o[g][k];
+            if (o > bestv) { best = k; bestv = o; }        // first maximum, as np.argmax
+        }
+        action[(size_t)b * N + n] = best;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -256,6 +256,25 @@ class Engine:
             _ffi.ptr_u8(ok) if self.N else None))
         return alive.astype(bool), ok.astype(bool)
 
+    def run_episode_mlp(self, L_schedule, params, member_a=None, member_b=None, split=None, L_init=0.75):
+        """K device-resident steps with MLP policies: agents [0, split) of world b use parameter set
+        member_a[b], agents [split, N) member_b[b].  Returns (reward (K,B,N,1) float64, done (K,B,N,1) bool)
+        exactly as K calls of env.step would (ref step :486-492)."""
+        Ls = np.ascontiguousarray(L_schedule, dtype=np.float64)
+        K = Ls.shape[0]
+        w = np.ascontiguousarray(params, dtype=np.float64).reshape(-1, 1808)
+        ma = None if member_a is None else np.ascontiguousarray(member_a, dtype=np.int32)
+        mb = None if member_b is None else np.ascontiguousarray(member_b, dtype=np.int32)
+        for m in (ma, mb):
+            if m is not None and m.shape != (self.B,):
+                raise ValueError(f"member maps must have shape {(self.B,)}")
+        split = self.N // 2 if split is None else int(split)
+        reward = np.zeros((K, self.B, self.N, 1))
+        done = np.zeros((K, self.B, self.N, 1), dtype=np.uint8)
+        check(self._lib.dw_run_episode_mlp(self._h, K, _ffi.ptr_d(Ls), _ffi.ptr_d(w), w.shape[0], _ffi.ptr_i(ma),
+                                           _ffi.ptr_i(mb), split, float(L_init), _ffi.ptr_d(reward), _ffi.ptr_u8(done)))
+        return reward, done.astype(bool)
+
     # -- plumbing -----------------------------------------------------------------------------
     def set_stream(self, hip_stream_ptr: int):
         check(self._lib.dw_set_stream(self._h, C.c_void_p(hip_stream_ptr)))

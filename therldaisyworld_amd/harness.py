@@ -126,39 +126,68 @@ def simulate_lifespan(env, agent, chunk=32, use_device_loop=True, obs=None):
             return done_at, agents_done_at
 
 
-def get_fitness(env, agent, adversary, max_steps=768):
+def _advance_host_scalars(env, executed):
+    """L, step_count and the ramp bookkeeping of `executed` steps the device has already taken."""
+    for _ in range(executed):
+        env._L_pass = env.L
+        env.L = env.update_L(env.L)
+    env._invalidate()
+
+
+def _mlp_chunks(env, params, member_a, member_b, half, max_steps, chunk, stop_after):
+    """The step loop shared by the two fitness harnesses: chunks of steps device-resident
+    (``dw_run_episode_mlp``), the reference's per-step float64 bookkeeping done by `stop_after(reward,
+    done) -> bool` on the downloaded (B,N,1) rewards / done flags in step order.  When the episode ends
+    inside a chunk, the chunk is replayed from a device-side snapshot for exactly the executed steps, so
+    the environment is left where the reference's loop leaves it."""
+    eng = env._engine
+    first, finished = True, False
+    while not finished and env.step_count < max_steps:
+        K = 1 if first else min(int(chunk), max_steps - env.step_count)    # step 1 starts from the un-quantised state
+        Ls = _luminosity_schedule(env, K)
+        env._sync_to_device()
+        if K > 1:
+            eng.snapshot_save()
+        rewards, dones = eng.run_episode_mlp(Ls, params, member_a, member_b, half, env._L_pass)
+        executed = K
+        for t in range(K):
+            if stop_after(rewards[t] * (rewards[t] > 0), dones[t]):
+                executed, finished = t + 1, True
+                break
+        if executed < K:
+            eng.snapshot_restore()
+            eng.run_episode_mlp(Ls[:executed], params, member_a, member_b, half, env._L_pass)
+        _advance_host_scalars(env, executed)
+        first = False
+
+
+def get_fitness(env, agent, adversary, max_steps=768, chunk=64):
     """ref SimpleGaussianES.get_fitness (daisy/evo/sges.py:144-181): one episode in which the first half
     of every world's agents is driven by `agent` and the second half by `adversary` (both MLP policies);
-    returns (fitness, total_steps, done_at) exactly as the reference computes them.  The policies run on
-    the device from the device-resident state (`policy_mlp`), the actions never leave the device; only the
-    (B,N) rewards come back per step for the reference's float64 mean."""
+    returns (fitness, total_steps, done_at) exactly as the reference computes them.  Observations,
+    policies, grazing and physics stay on the device for `chunk` steps at a time; only the (K,B,N) rewards
+    and done flags come back, for the reference's float64 means in step order."""
     agent.reset()
     obs = env.reset()
     B, N = obs.shape[0], obs.shape[1]
     half = N // 2
-    eng = env._engine
-    done_at = np.zeros((B, N, 1), dtype=int)
-    total_steps = 0
-    sum_reward = 0.0
-    all_done = False
-    while not all_done and env.step_count < max_steps:
-        agent.act_on_device(env, 0, half)
-        adversary.act_on_device(env, half, N)
-        eng.step_device_actions(env.L)
-        env._L_pass = env.L
-        env._invalidate()
-        reward, done = eng.reward_done()
-        reward = reward * (reward > 0)
+    params = np.stack([agent.get_parameters(), adversary.get_parameters()])
+    member_a, member_b = np.zeros(B, dtype=np.int32), np.ones(B, dtype=np.int32)
+    acc = {"done_at": np.zeros((B, N, 1), dtype=int), "total_steps": 0, "sum_reward": 0.0}
+
+    def stop_after(reward, done):
         all_done = (np.ones_like(done).sum() - done.sum()) == 0
-        done_at += (1 - 1 * done)
-        sum_reward += (reward[:, :half]).mean()
-        total_steps = total_steps + (1 - 1 * done)
-        env.L = env.update_L(env.L)
-    fitness = sum_reward / (B * N)
-    return fitness, total_steps, done_at.tolist()
+        acc["done_at"] += (1 - 1 * done)
+        acc["sum_reward"] += (reward[:, :half]).mean()
+        acc["total_steps"] = acc["total_steps"] + (1 - 1 * done)
+        return all_done
+
+    _mlp_chunks(env, params, member_a, member_b, half, max_steps, chunk, stop_after)
+    fitness = acc["sum_reward"] / (B * N)
+    return fitness, acc["total_steps"], acc["done_at"].tolist()
 
 
-def get_fitness_population(env, population, adversary_of=None, worlds_per_member=32, max_steps=768):
+def get_fitness_population(env, population, adversary_of=None, worlds_per_member=32, max_steps=768, chunk=64):
     """All members of an evolution-strategy population evaluated as ONE batched ensemble (SURVEY.md §8f
     N3; the reference runs `get_fitness` once per member and farms members out to MPI workers,
     daisy/evo/sges.py:314-349).  `population` is a list of MLP policies (or a (P,1808) array);
@@ -178,30 +207,24 @@ def get_fitness_population(env, population, adversary_of=None, worlds_per_member
     obs = env.reset()
     B, N = obs.shape[0], obs.shape[1]
     half = N // 2
-    eng = env._engine
     member = np.repeat(np.arange(P), worlds_per_member).astype(np.int32)
     adv_member = adversary_of[member].astype(np.int32)
     done_at = np.zeros((B, N, 1), dtype=int)
     total_steps = np.zeros((B, N, 1), dtype=int)
     sum_reward = np.zeros(P)
     running = np.ones(P, dtype=bool)
-    while running.any() and env.step_count < max_steps:
-        env._sync_to_device()
-        eng.policy_mlp_population(params, member, 0, half, env._L_pass)
-        eng.policy_mlp_population(params, adv_member, half, N, env._L_pass)
-        eng.step_device_actions(env.L)
-        env._L_pass = env.L
-        env._invalidate()
-        reward, done = eng.reward_done()
-        reward = reward * (reward > 0)
+
+    def stop_after(reward, done):
         live = np.repeat(running, worlds_per_member)[:, None, None]
-        done_at += live * (1 - 1 * done)
-        total_steps += live * (1 - 1 * done)
+        done_at[...] += live * (1 - 1 * done)
+        total_steps[...] += live * (1 - 1 * done)
         r = reward.reshape(P, worlds_per_member, N, 1)
         d = done.reshape(P, worlds_per_member, N, 1)
-        sum_reward += running * r[:, :, :half].mean(axis=(1, 2, 3))
-        running &= ~d.reshape(P, -1).all(axis=1)
-        env.L = env.update_L(env.L)
+        sum_reward[...] += running * r[:, :, :half].mean(axis=(1, 2, 3))
+        running[...] &= ~d.reshape(P, -1).all(axis=1)
+        return not running.any()
+
+    _mlp_chunks(env, params, member, adv_member, half, max_steps, chunk, stop_after)
     fitness = sum_reward / (worlds_per_member * N)
     return [(fitness[m], total_steps[m * worlds_per_member:(m + 1) * worlds_per_member],
              done_at[m * worlds_per_member:(m + 1) * worlds_per_member].tolist()) for m in range(P)]
