@@ -4,7 +4,7 @@ The policy maps a (B,N,7,3,3) observation to a (B,N,1) action code; it is O(B*N*
 its *RNG draws* define same-seed parity (one ``np.random.rand()`` per call for the whole batch, then
 ``np.random.randint(9)`` per agent on the random branch), so this mirror keeps both on the host
 NumPy stream.  The device-resident twin of the deterministic branch is ``Engine.policy_greedy``
-(csrc/dw_kernels.hpp ``policy_greedy``), used by ``therldaisyworld_amd.harness`` to run whole
+(csrc/dw_agents.hpp ``policy_greedy``), used by ``therldaisyworld_amd.harness`` to run whole
 episodes without shipping observations to the host.
 """
 import numpy as np

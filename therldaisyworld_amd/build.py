@@ -13,7 +13,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdaisyworld_hip.so")
 SOURCES = ["dw_api.hip"]
-DEPS = ["dw_api.hip", "dw_kernels.hpp", "dw_physics.hpp", os.path.join("..", "..", "include", "daisyworld_hip.h")]
+DEPS = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp"))) + \
+       [os.path.join("..", "..", "include", "daisyworld_hip.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra",
          "-Wno-unused-parameter"]
 

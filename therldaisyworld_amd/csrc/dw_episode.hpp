@@ -1,0 +1,234 @@
+// dw_episode.hpp — episode_small: device-resident episode loop (policy, grazing, physics, flags for K
+// steps in one launch) for worlds that fit LDS (H*W <= 4096).
+#pragma once
+#include "dw_common.hpp"
+
+namespace dw {
+
+// ---------------------------------------------------------------------------------------------
+// episode_small — device-resident episode loop for small worlds (H*W <= 4096: the README sweep's
+// 8x8 grids up to C1's 64x64).  SURVEY.md §8(f) row N1.
+//
+// A workgroup keeps `wpb` whole worlds (both planes, ping-pong) and their agents in LDS and runs
+// K consecutive environment steps without leaving the chip: per step
+//     policy (ref Greedy.__call__, agents/greedy.py:14-36, or host-drawn random actions)
+//   -> update_agents (ref :181-244, one lane per world, agents in order)
+//   -> forward (ref :434-461; toroidal 3x3 stencil straight from LDS; exact mode re-evaluates
+//      near-tie cells in float64 on the spot)
+//   -> per-world reductions + the per-step flags the notebook's lifespan harness counts
+//      (world alive: max cover > 0.005; agent alive: reward >= 0.1; cell 2:46-52).
+// Luminosity-dependent coefficients of all K steps are precomputed on the host (P32[t], Ls[t]).
+// On exit the current planes, the pre-last-step planes (for observations / env.grid), the agents and
+// the reductions go back to global memory, so the ordinary entry points continue from there.
+// ---------------------------------------------------------------------------------------------
+enum { kPolicyArgmax = 0, kPolicyArgmin = 1, kPolicyZeros = 2, kPolicyTable = 3, kPolicySkipAgents = 4 };
+
+struct EpisodeIO {
+    float* L;                       // [B][C] current planes (in/out)
+    float* D;
+    float* prevL;                   // [B][C] out: state before the last step (after its grazing)
+    float* prevD;
+    int* idx;                       // [B][N][2] in/out
+    double* st;                     // [B][N] in/out
+    const PhysF32* P32;             // [K]
+    const double* Ls;               // [K]
+    const unsigned char* use_table; // [K]  1 = take this step's actions from `table` (epsilon branch)
+    const signed char* table;       // [K][B][N] host-drawn action codes
+    unsigned char* world_alive;     // [K][B] out
+    unsigned char* agent_ok;        // [K][B][N] out
+    StatsDev* stats;                // [B] out: reductions after the last step
+    unsigned long long* fixups;     // out: float64 re-evaluations of the last step (summed)
+};
+
+template <bool EXACT>
+__global__ __launch_bounds__(256) void episode_small(EpisodeIO io, int B, int N, int H, int W, int wpb, int K,
+                                                     int policy_mode, int obs_mask, double agent_gamma,
+                                                     unsigned int thr, PhysF64 P64) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int C = H * W;
+    const int tpw = 256 / wpb;                                   // threads per world
+    const int tid = threadIdx.x, w = tid / tpw, lt = tid - w * tpw;
+    const int b = blockIdx.x * wpb + w;
+    const bool valid = b < B;
+    // LDS carve-up per world: planes [2 buffers][2 species][C] floats | agent state doubles | idx | act | red
+    const size_t world_bytes = ((size_t)16 * C + (size_t)N * 8 + (size_t)N * 12 + 16 + 15) / 16 * 16;
+    unsigned char* base = smem + (size_t)w * world_bytes;
+    float* planes = reinterpret_cast<float*>(base);
+    double* ast = reinterpret_cast<double*>(base + (size_t)16 * C);
+    int* aidx = reinterpret_cast<int*>(base + (size_t)16 * C + (size_t)N * 8);
+    int* act = aidx + 2 * N;
+    unsigned int* red = reinterpret_cast<unsigned int*>(act + N);   // max, sum_l, sum_d, fixups
+    float* curL = planes;
+    float* curD = planes + C;
+    float* nxtL = planes + 2 * C;
+    float* nxtD = planes + 3 * C;
+
+    if (valid) {
+        for (int c = lt; c < C; c += tpw) {
+            curL[c] = io.L[(size_t)b * C + c];
+            curD[c] = io.D[(size_t)b * C + c];
+        }
+        for (int n = lt; n < N; n += tpw) {
+            ast[n] = io.st[(size_t)b * N + n];
+            aidx[2 * n] = io.idx[((size_t)b * N + n) * 2];
+            aidx[2 * n + 1] = io.idx[((size_t)b * N + n) * 2 + 1];
+        }
+        if (lt < 4) red[lt] = 0;
+    }
+    __syncthreads();
+
+    for (int t = 0; t < K; ++t) {
+        // ---- policy: action of each agent for this step, from the state it observes ----
+        if (valid && policy_mode != kPolicySkipAgents) {
+            for (int n = lt; n < N; n += tpw) {
+                int a = 0;
+                if (policy_mode == kPolicyTable || (policy_mode != kPolicyZeros && io.use_table[t])) {
+                    a = io.table[((size_t)t * B + b) * N + n];
+                } else if (policy_mode != kPolicyZeros) {
+                    const int ar = aidx[2 * n], ac = aidx[2 * n + 1];
+                    const int cand[4] = {3, 1, 7, 5};             // (r,c-1) (r-1,c) (r+1,c) (r,c+1)
+                    int best = 0;
+                    double bestv = 0.0;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int k = cand[i];
+                        double v = 0.0;
+                        if ((obs_mask >> k) & 1) {
+                            const int r = (ar + (k / 3 - 1) + H) % H, c = (ac + (k % 3 - 1) + W) % W;
+                            v = (double)curL[r * W + c] / 1000.0 + (double)curD[r * W + c] / 1000.0;
+                        }
+                        if (i == 0 || (policy_mode == kPolicyArgmin ? v < bestv : v > bestv)) { best = i; bestv = v; }
+                    }
+                    a = 4 + best;
+                }
+                act[n] = a;
+            }
+        }
+        __syncthreads();
+        // ---- update_agents (ref :181-244): one lane per world, agents in order ----
+        if (valid && lt == 0 && N > 0 && policy_mode != kPolicySkipAgents) {
+            for (int n = 0; n < N; ++n) ast[n] -= agent_gamma;
+            for (int n = 0; n < N; ++n) {
+                double s = ast[n];
+                if (s > 0.0) {
+                    const int a = act[n];
+                    int r = aidx[2 * n], c = aidx[2 * n + 1];
+                    if (a != 8) {
+                        const int m = ((a % 4) + 4) % 4;
+                        if (m == 0) c -= 1; else if (m == 1) r -= 1; else if (m == 2) r += 1; else c += 1;
+                    }
+                    r = ((r % H) + H) % H;
+                    c = ((c % W) + W) % W;
+                    aidx[2 * n] = r;
+                    aidx[2 * n + 1] = c;
+                    if (a > 4) {
+                        const int o = r * W + c;
+                        s += (double)curL[o] / 1000.0 + (double)curD[o] / 1000.0;
+                        curL[o] = 0.f;
+                        curD[o] = 0.f;
+                        ast[n] = s;
+                    }
+                }
+            }
+            for (int n = 0; n < N; ++n) {
+                const double s = ast[n];
+                ast[n] = s < 0.0 ? 0.0 : (s > 1.0 ? 1.0 : s);
+            }
+        }
+        __syncthreads();
+        // ---- forward ----
+        const PhysF32 P = io.P32[t];
+        PhysF64 Q = P64;
+        Q.L = io.Ls[t];
+        float tmax = 0.f, tsl = 0.f, tsd = 0.f;
+        unsigned int nfix = 0;
+        if (valid) {
+            for (int c = lt; c < C; c += tpw) {
+                const int r = c / W, cc = c - r * W;
+                const int ru = (r == 0 ? H - 1 : r - 1) * W, rm = r * W, rd = (r == H - 1 ? 0 : r + 1) * W;
+                const int cl = cc == 0 ? W - 1 : cc - 1, cr = cc == W - 1 ? 0 : cc + 1;
+                const float li = curL[rm + cc], di = curD[rm + cc];
+                const float El = (curL[ru + cc] + curL[rd + cc]) + (curL[rm + cl] + curL[rm + cr]);
+                const float Cl = (curL[ru + cl] + curL[rd + cl]) + (curL[ru + cr] + curL[rd + cr]);
+                const float Ed = (curD[ru + cc] + curD[rd + cc]) + (curD[rm + cl] + curD[rm + cr]);
+                const float Cd = (curD[ru + cl] + curD[rd + cl]) + (curD[ru + cr] + curD[rd + cr]);
+                const GrowthF32 g = growth_f32<EXACT>(P, li, di, El, Cl, Ed, Cd);
+                float kl, kd;
+                if (EXACT) {
+                    bool tl, td;
+                    kl = finish_exact(P, li, g.gql, g.dKl, g.oml, tl);
+                    kd = finish_exact(P, di, g.gqd, g.dKd, g.omd, td);
+                    if (tl || td) {
+                        const int rows[3] = {ru, rm, rd}, cols[3] = {cl, cc, cr};
+                        unsigned int wv[9];
+#pragma unroll
+                        for (int a = 0; a < 3; ++a)
+#pragma unroll
+                            for (int e = 0; e < 3; ++e)
+                                wv[a * 3 + e] = (unsigned)curL[rows[a] + cols[e]] | ((unsigned)curD[rows[a] + cols[e]] << 16);
+                        const NewCoverF64 o = cell_f64_lean(Q, wv);
+                        kl = (float)dw_round3_k(o.nl);
+                        kd = (float)dw_round3_k(o.nd);
+                        ++nfix;
+                    }
+                } else {
+                    kl = finish_fast(li, g.gql);
+                    kd = finish_fast(di, g.gqd);
+                }
+                nxtL[c] = kl;
+                nxtD[c] = kd;
+                tmax = fmaxf(tmax, fmaxf(kl, kd));
+                tsl += kl;
+                tsd += kd;
+            }
+        }
+        // per-world reductions: wavefront shuffles when a wave belongs to one world, LDS atomics across waves
+        {
+            const float m = tpw >= 64 ? wave_max(tmax) : tmax;
+            const float sl = tpw >= 64 ? wave_sum(tsl) : tsl;
+            const float sd = tpw >= 64 ? wave_sum(tsd) : tsd;
+            if (valid && (tpw < 64 || (tid & 63) == 0)) {
+                atomicMax(&red[0], (unsigned int)m);
+                atomicAdd(&red[1], (unsigned int)sl);
+                atomicAdd(&red[2], (unsigned int)sd);
+            }
+            if (EXACT && valid && nfix) atomicAdd(&red[3], nfix);
+        }
+        __syncthreads();
+        { float* x = curL; curL = nxtL; nxtL = x; x = curD; curD = nxtD; nxtD = x; }
+        // ---- per-step flags of the lifespan harness; final reductions ----
+        if (valid) {
+            if (lt == 0) io.world_alive[(size_t)t * B + b] = red[0] > thr ? 1 : 0;
+            for (int n = lt; n < N; n += tpw) {
+                const double s = ast[n];
+                const double rw = s * (s > 0.0 ? 1.0 : 0.0);
+                io.agent_ok[((size_t)t * B + b) * N + n] = rw < 0.1 ? 0 : 1;
+            }
+            if (t == K - 1 && lt == 0) {
+                io.stats[b].max_k = red[0];
+                io.stats[b].sum_l = red[1];
+                io.stats[b].sum_d = red[2];
+                if (EXACT && red[3]) atomicAdd(io.fixups, (unsigned long long)red[3]);
+            }
+        }
+        __syncthreads();
+        if (valid && lt < 4) red[lt] = 0;
+        __syncthreads();
+    }
+
+    if (valid) {
+        for (int c = lt; c < C; c += tpw) {
+            io.L[(size_t)b * C + c] = curL[c];
+            io.D[(size_t)b * C + c] = curD[c];
+            io.prevL[(size_t)b * C + c] = nxtL[c];
+            io.prevD[(size_t)b * C + c] = nxtD[c];
+        }
+        for (int n = lt; n < N; n += tpw) {
+            io.st[(size_t)b * N + n] = ast[n];
+            io.idx[((size_t)b * N + n) * 2] = aidx[2 * n];
+            io.idx[((size_t)b * N + n) * 2 + 1] = aidx[2 * n + 1];
+        }
+    }
+}
+
+}  // namespace dw

@@ -1,0 +1,223 @@
+// dw_state_io.hpp — state in and out of the device layout: the reference's 7-channel float64 grid and
+// its side-effect caches (materialise), the tie-bound audit, Philox initial states, plane conversions and
+// the stand-alone per-world reductions.
+#pragma once
+#include "dw_common.hpp"
+
+namespace dw {
+
+// ---------------------------------------------------------------------------------------------
+// materialise — the reference's 7-channel float64 grid.
+//   after a step (POST=true): prev = pre-step covers (post-graze), cur = quantised new covers:
+//       ch0 = round3(p - nl - nd) from the un-rounded clipped covers (ref :450,452),
+//       ch1/2 = cur/1000, ch3..5 = round3(T, T_light, T_dark) of prev (ref :446-448), ch6 = 0.
+//   after an upload (POST=false): prev = the initial covers; ch0..2 un-rounded, ch3..5 un-rounded
+//       temperatures (ref :310-323).
+// caches (optional): temps[3], betas[3], growth[2], temp_effective — un-rounded (ref :345-419).
+// Agent states are written into channel 4 afterwards by agents_stamp (ref :454-459).
+// ---------------------------------------------------------------------------------------------
+template <typename PrevT, bool POST>
+__global__ __launch_bounds__(256) void materialise(const PrevT* __restrict__ pL,
+                                                   const PrevT* __restrict__ pD,
+                                                   const float* __restrict__ cL,
+                                                   const float* __restrict__ cD, int H, int W,
+                                                   PhysF64 P, double* __restrict__ grid7,
+                                                   double* __restrict__ temps,
+                                                   double* __restrict__ betas,
+                                                   double* __restrict__ growth,
+                                                   double* __restrict__ teff) {
+    const int b = blockIdx.y;
+    const int cell = blockIdx.x * 256 + threadIdx.x;
+    if (cell >= H * W) return;
+    const size_t n = (size_t)H * W, woff = (size_t)b * n;
+    const int r = cell / W, c = cell - r * W;
+    double l9[9], d9[9];
+    gather9(pL + woff, H, W, r, c, l9);
+    gather9(pD + woff, H, W, r, c, d9);
+    const CellF64 o = cell_f64(P, l9, d9);
+    if (grid7) {
+        double* g = grid7 + (size_t)b * 7 * n + cell;
+        if (POST) {
+            g[0 * n] = dw_round3_k(P.p - o.nl - o.nd) / 1000.0;
+            g[1 * n] = (double)cL[woff + cell] / 1000.0;
+            g[2 * n] = (double)cD[woff + cell] / 1000.0;
+            g[3 * n] = dw_round3_k(o.T) / 1000.0;
+            g[4 * n] = dw_round3_k(o.Tl) / 1000.0;
+            g[5 * n] = dw_round3_k(o.Td) / 1000.0;
+        } else {
+            g[0 * n] = P.p - l9[4] - d9[4];
+            g[1 * n] = l9[4];
+            g[2 * n] = d9[4];
+            g[3 * n] = o.T;
+            g[4 * n] = o.Tl;
+            g[5 * n] = o.Td;
+        }
+        g[6 * n] = 0.0;
+    }
+    if (temps) {
+        double* t = temps + (size_t)b * 3 * n + cell;
+        t[0] = o.T; t[n] = o.Tl; t[2 * n] = o.Td;
+    }
+    if (betas) {
+        double* t = betas + (size_t)b * 3 * n + cell;
+        t[0] = o.b; t[n] = o.bl; t[2 * n] = o.bd;
+    }
+    if (growth) {
+        double* t = growth + (size_t)b * 2 * n + cell;
+        t[0] = o.gl; t[n] = o.gd;
+    }
+    if (teff) teff[woff + cell] = o.Te;
+}
+
+// ref forward :454-459 — agent states into channel 4 at agent cells, in agent order (last wins)
+__global__ void agents_stamp(double* __restrict__ grid7, const int* __restrict__ idx,
+                             const double* __restrict__ st, int B, int N, int H, int W) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const size_t n = (size_t)H * W;
+    for (int a = 0; a < N; ++a) {
+        const int r = idx[((size_t)b * N + a) * 2], c = idx[((size_t)b * N + a) * 2 + 1];
+        grid7[(size_t)b * 7 * n + 4 * n + (size_t)r * W + c] = st[(size_t)b * N + a];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// tie_audit — evidence for the exact mode's error bound.  For every cell of a quantised state:
+// float32 per-mille growth gq32 (the hot kernels' arithmetic, split coefficient chains) against the
+// float64 growth of cell_f64, and the per-cell bound eps the tie test would use.  Reduces
+//   out[0] = max |gq32 - gq64| (quanta)      out[1] = max (|gq32 - gq64| / eps)   (< 1 <=> bound holds)
+//   out[2] = number of cells the tie test flags   out[3] = number of cells audited
+// (both species count).  Non-negative doubles order like their bit patterns: atomicMax on u64.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tie_audit(const float* __restrict__ L, const float* __restrict__ D, int H, int W,
+                                                 PhysF32 P, PhysF64 P64, unsigned long long* __restrict__ out) {
+    const int b = blockIdx.y;
+    const int cell = blockIdx.x * 256 + threadIdx.x;
+    if (cell >= H * W) return;
+    const size_t woff = (size_t)b * H * W;
+    const float* pl = L + woff;
+    const float* pd = D + woff;
+    const int r = cell / W, c = cell - r * W;
+    const int ru = r == 0 ? H - 1 : r - 1, rd = r == H - 1 ? 0 : r + 1;
+    const int cl = c == 0 ? W - 1 : c - 1, cr = c == W - 1 ? 0 : c + 1;
+#define DW_AT(p, rr, cc) (p)[(size_t)(rr) * W + (cc)]
+    const float li = DW_AT(pl, r, c), di = DW_AT(pd, r, c);
+    const float El = (DW_AT(pl, ru, c) + DW_AT(pl, rd, c)) + (DW_AT(pl, r, cl) + DW_AT(pl, r, cr));
+    const float Cl = (DW_AT(pl, ru, cl) + DW_AT(pl, rd, cl)) + (DW_AT(pl, ru, cr) + DW_AT(pl, rd, cr));
+    const float Ed = (DW_AT(pd, ru, c) + DW_AT(pd, rd, c)) + (DW_AT(pd, r, cl) + DW_AT(pd, r, cr));
+    const float Cd = (DW_AT(pd, ru, cl) + DW_AT(pd, rd, cl)) + (DW_AT(pd, ru, cr) + DW_AT(pd, rd, cr));
+#undef DW_AT
+    const GrowthF32 g = growth_f32<true>(P, li, di, El, Cl, Ed, Cd);
+    double l9[9], d9[9];
+    gather9(pl, H, W, r, c, l9);
+    gather9(pd, H, W, r, c, d9);
+    const CellF64 o = cell_f64(P64, l9, d9);
+    const double g64[2] = {P64.dt * o.gl * 1000.0, P64.dt * o.gd * 1000.0};
+    const float g32[2] = {g.gql, g.gqd};
+    const float dK[2] = {g.dKl, g.dKd};
+    const float om[2] = {g.oml, g.omd};
+    double max_err = 0.0, max_ratio = 0.0;
+    unsigned long long flagged = 0;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const float thr = fmaf(-fabsf(dK[k]), fmaf(P.eK1, om[k], P.eK0), fmaf(-P.eA, fabsf(g32[k]), P.tie_lo));
+        const double eps = 0.5 - (double)thr;
+        const double err = fabs((double)g32[k] - g64[k]);
+        max_err = fmax(max_err, err);
+        max_ratio = fmax(max_ratio, err / eps);
+        const float rr = __builtin_rintf(g32[k]);
+        flagged += fabsf(g32[k] - rr) > thr ? 1ull : 0ull;
+    }
+    atomicMax(&out[0], (unsigned long long)__double_as_longlong(max_err));
+    atomicMax(&out[1], (unsigned long long)__double_as_longlong(max_ratio));
+    if (flagged) atomicAdd(&out[2], flagged);
+    atomicAdd(&out[3], 2ull);
+}
+
+// ---------------------------------------------------------------------------------------------
+// init_random — ref initialize_grid :287-302 / initialize_agents :175-179 with Philox4x32-10.
+// counter = (cell lo, cell hi, world lo, world hi), key = seed.  One call per cell gives the four
+// uniforms (U1_dark, U2_dark, U1_light, U2_light); the reference draws dark first.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void init_random_cells(float* __restrict__ L, float* __restrict__ D,
+                                                         int H, int W, long long world_offset,
+                                                         unsigned long long seed, float light_prop,
+                                                         float dark_prop, float ial, float iad) {
+    const int b = blockIdx.y;
+    const int cell = blockIdx.x * 256 + threadIdx.x;
+    if (cell >= H * W) return;
+    const unsigned long long world = (unsigned long long)(world_offset + b);
+    uint32_t r[4];
+    philox4x32_10((uint32_t)cell, 0u, (uint32_t)world, (uint32_t)(world >> 32), (uint32_t)seed,
+                  (uint32_t)(seed >> 32), r);
+    const float d = (u01(r[0]) < dark_prop) ? iad * u01(r[1]) : 0.f;
+    const float l = (u01(r[2]) < light_prop) ? ial * u01(r[3]) : 0.f;
+    const size_t o = (size_t)b * H * W + cell;
+    L[o] = l * 1000.f;
+    D[o] = d * 1000.f;
+}
+
+__global__ void init_random_agents(int* __restrict__ idx, double* __restrict__ st, int B, int N, int H,
+                                   int W, long long world_offset, unsigned long long seed) {
+    const int an = blockIdx.x * blockDim.x + threadIdx.x;
+    if (an >= B * N) return;
+    const int b = an / N, a = an - b * N;
+    const unsigned long long world = (unsigned long long)(world_offset + b);
+    uint32_t r[4];
+    philox4x32_10((uint32_t)a, 0x80000000u, (uint32_t)world, (uint32_t)(world >> 32), (uint32_t)seed,
+                  (uint32_t)(seed >> 32), r);
+    idx[(size_t)an * 2 + 0] = (int)(((unsigned long long)r[0] * (unsigned)H) >> 32);
+    idx[(size_t)an * 2 + 1] = (int)(((unsigned long long)r[1] * (unsigned)W) >> 32);
+    st[an] = 1.0;
+}
+
+// plane conversions
+__global__ void f64_to_permille(const double* __restrict__ in, float* __restrict__ out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (float)(in[i] * 1000.0);
+}
+__global__ void f32nat_to_permille(const float* __restrict__ in, float* __restrict__ out, size_t n,
+                                   int quantise) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const float k = in[i] * 1000.f;
+        out[i] = quantise ? __builtin_rintf(k) : k;
+    }
+}
+__global__ void permille_to_f64(const float* __restrict__ in, double* __restrict__ out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (double)in[i] / 1000.0;
+}
+
+// stats of an arbitrary state (used after uploads / init so that dw_reduce is always valid)
+constexpr int kStatsChunk = 4096;
+template <typename T>
+__global__ __launch_bounds__(256) void stats_only(const T* __restrict__ L, const T* __restrict__ D,
+                                                  int H, int W, StatsDev* __restrict__ stats) {
+    // a workgroup reduces kStatsChunk cells of world blockIdx.y (coalesced, stride 256): three atomics per
+    // wave per 4096 cells instead of per 64 (the per-world counters are contended)
+    const int b = blockIdx.y;
+    const int n = H * W;
+    const int base = blockIdx.x * kStatsChunk;
+    float m = 0.f, sl = 0.f, sd = 0.f;
+    for (int i = threadIdx.x; i < kStatsChunk; i += 256) {
+        const int cell = base + i;
+        if (cell < n) {
+            const float kl = to_permille(L[(size_t)b * n + cell]);
+            const float kd = to_permille(D[(size_t)b * n + cell]);
+            m = fmaxf(m, fmaxf(kl, kd));
+            sl += kl;
+            sd += kd;
+        }
+    }
+    m = wave_max(m);
+    sl = wave_sum(sl);
+    sd = wave_sum(sd);
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(&stats[b].max_k, (unsigned int)ceilf(m));
+        atomicAdd(&stats[b].sum_l, (unsigned long long)(sl + 0.5f));
+        atomicAdd(&stats[b].sum_d, (unsigned long long)(sd + 0.5f));
+    }
+}
+
+}  // namespace dw

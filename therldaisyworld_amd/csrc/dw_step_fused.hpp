@@ -1,0 +1,381 @@
+// dw_step_fused.hpp — step_stream_fused2[_exact]: two consecutive steps per HBM round trip (temporal
+// blocking inside the wave-strip design; dw_step_n on wide grids without agent updates).
+#pragma once
+#include "dw_step_stream.hpp"
+
+namespace dw {
+
+// ---------------------------------------------------------------------------------------------
+// step_stream_fused2 — TWO consecutive steps per HBM round trip (float32-only mode, no agent
+// update between the steps: dw_step_n on wide grids).  Temporal blocking inside the wave-strip
+// design: as a wave marches down its strip, every new input row yields one row of step-1 results
+// (kept only in a second 3-row register window, never written to memory) and, one row behind it,
+// one row of step-2 results, which is stored.  HBM traffic per cell-update drops to ~8.5 B
+// (measured by PMC, profiles/), and the kernel becomes VALU-bound.
+//
+// Horizontal neighbours of step-1 results come from adjacent lanes by DPP like the inputs do.
+//   ROT (W == 256): the wave spans the whole torus row, all 64 lanes produce output.
+//   OVL (other W):  strips overlap by one lane (4 columns) on each side: lanes 0 and 63 load and
+//                   compute step 1 but only lanes 1..62 (248 columns) produce output; no halo loads.
+// Vertically a strip of SR output rows reads SR+4 input rows and computes SR+2 step-1 rows.
+// ---------------------------------------------------------------------------------------------
+struct FusedGeom {
+    int B, H, W;
+    int SR;                   // output rows per wave-strip
+    int ncs, nrs;             // column / row strips per world
+    int nstrips, nwg, chunk;
+    int cols_per_strip;       // 256 (ROT) or 248 (OVL)
+    int qcap, mcap;           // queue / mismatch-list capacities in use (tests shrink them)
+};
+
+// float64 step-1 value of grid cell (r, c) (any integers: wrapped onto the torus) from the input planes,
+// as a packed light | dark << 16 word
+__device__ inline unsigned int exact1_word(const float* __restrict__ pL, const float* __restrict__ pD, int H, int W,
+                                           int r, int c, const PhysF64& Pa) {
+    const int rr = ((r % H) + H) % H, cc = ((c % W) + W) % W;
+    const int ru = rr == 0 ? H - 1 : rr - 1, rd = rr == H - 1 ? 0 : rr + 1;
+    const int cl = cc == 0 ? W - 1 : cc - 1, cr = cc == W - 1 ? 0 : cc + 1;
+    const int rows[3] = {ru, rr, rd}, cols[3] = {cl, cc, cr};
+    unsigned int w1[9];
+#pragma unroll
+    for (int x = 0; x < 3; ++x)
+#pragma unroll
+        for (int y = 0; y < 3; ++y) {
+            const size_t o = (size_t)rows[x] * W + cols[y];
+            w1[x * 3 + y] = (unsigned)pL[o] | ((unsigned)pD[o] << 16);
+        }
+    const NewCoverF64 s1 = cell_f64_lean(Pa, w1);
+    return (unsigned)dw_round3_k(s1.nl) | ((unsigned)dw_round3_k(s1.nd) << 16);
+}
+
+// exact two-step value of one cell straight from the input planes, all in float64: nine step-1
+// evaluations (luminosity La) feeding one step-2 evaluation (Lb).  Used only to repair the rare
+// dependents of a float32 step-1 mismatch and as the overflow fallback.
+__device__ inline void exact2_cell(const float* __restrict__ pL, const float* __restrict__ pD, int H, int W, int r,
+                                   int c, const PhysF64& Pa, const PhysF64& Pb, float& kl, float& kd) {
+    unsigned int w2[9];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            int rr = r + a - 1, cc = c + e - 1;
+            rr = rr < 0 ? rr + H : (rr >= H ? rr - H : rr);
+            cc = cc < 0 ? cc + W : (cc >= W ? cc - W : cc);
+            const int ru = rr == 0 ? H - 1 : rr - 1, rd = rr == H - 1 ? 0 : rr + 1;
+            const int cl = cc == 0 ? W - 1 : cc - 1, cr = cc == W - 1 ? 0 : cc + 1;
+            const int rows[3] = {ru, rr, rd}, cols[3] = {cl, cc, cr};
+            unsigned int w1[9];
+#pragma unroll
+            for (int x = 0; x < 3; ++x)
+#pragma unroll
+                for (int y = 0; y < 3; ++y) {
+                    const size_t o = (size_t)rows[x] * W + cols[y];
+                    w1[x * 3 + y] = (unsigned)pL[o] | ((unsigned)pD[o] << 16);
+                }
+            const NewCoverF64 s1 = cell_f64_lean(Pa, w1);
+            w2[a * 3 + e] = (unsigned)dw_round3_k(s1.nl) | ((unsigned)dw_round3_k(s1.nd) << 16);
+        }
+    const NewCoverF64 s2 = cell_f64_lean(Pb, w2);
+    kl = (float)dw_round3_k(s2.nl);
+    kd = (float)dw_round3_k(s2.nd);
+}
+
+constexpr int kMismatchCap = 64;            // float32 step-1 mismatches per wave-strip held in LDS
+
+// EXACT variant (the default mode's dw_step_n on wide grids).  Both steps run in float32 with the
+// per-cell tie test; near-tie cells of BOTH steps are queued in the wave's LDS queue with their 3x3
+// payload (step 1: the inputs; step 2: the float32 step-1 values).  After the strip the same wave
+//   F1  re-evaluates every queued step-1 cell in float64; almost always the float32 value was right
+//       (~97 %); a cell where it was not is a MISMATCH,
+//   F2  re-evaluates every queued step-2 cell in float64 from its payload and patches the output,
+//   F3  for every mismatch recomputes, entirely in float64 from the input planes, the (up to) nine
+//       output cells that depend on it, and patches them (rare: ~0.01 % of cells).
+// A cell's output is therefore the float64 result whenever any float32 rounding on its dependency
+// cone was uncertain.  Queue / mismatch-list overflow: the whole strip is recomputed in float64.
+// Fused launches leave the per-world reductions untouched (dw_step_n always ends with a single step,
+// which recomputes them), they only keep the double-buffer protocol.
+template <bool ROT, bool EXACT>
+__device__ __forceinline__ void fused2_body(const float* __restrict__ inL, const float* __restrict__ inD,
+                                            float* __restrict__ outL, float* __restrict__ outD, const FusedGeom& G,
+                                            const PhysF32& P1, const PhysF32& P2, const PhysF64& P64,
+                                            const double& La, const double& Lb,
+                                            unsigned long long* __restrict__ zero_me, int zero_n) {
+    __shared__ uint4 s_queue[EXACT ? 4 * kWaveQueueCap * 3 : 1];
+    __shared__ unsigned int s_mm[EXACT ? 4 * kMismatchCap : 1];
+    const int bid = blockIdx.x;
+    const int wg = (bid & 7) * G.chunk + (bid >> 3);
+    if (wg >= G.nwg) return;
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    if (wg == 0)
+        for (int i = tid; i < zero_n; i += 256) zero_me[i] = 0ull;
+    const int s = wg * 4 + wv;
+    if (s >= G.nstrips) return;
+    uint4* q = s_queue + (EXACT ? wv * kWaveQueueCap * 3 : 0);
+    unsigned int* mm = s_mm + (EXACT ? wv * kMismatchCap : 0);
+    const int spw = G.nrs * G.ncs;
+    const int b = s / spw;
+    const int sw = s - b * spw;
+    const int rs = sw / G.ncs, cs = sw - rs * G.ncs;
+    const int r0 = rs * G.SR;
+    const int nr = min(G.SR, G.H - r0);
+    const size_t woff = (size_t)b * G.H * G.W;
+    const int c00 = ROT ? 0 : cs * 248 - 4;                     // grid column of local column 0 (may be -4)
+    int col = c00 + 4 * lane;
+    col = col < 0 ? col + G.W : col;
+    col = col >= G.W ? col - G.W : col;                         // W >= 256 > 252: one wrap suffices
+    const bool writes = ROT ? true : (lane >= 1 && lane <= 62 && cs * 248 + 4 * (lane - 1) < G.W);
+    // which of my four step-1 cells feed an output cell of this wave (exact mode: only their ties matter)
+    bool need1[4] = {true, true, true, true};
+    if (EXACT && !ROT) {
+        const bool wl = __builtin_amdgcn_update_dpp(0, writes ? 1 : 0, kDppWaveShr1, 0xf, 0xf, false) != 0;
+        const bool wr = __builtin_amdgcn_update_dpp(0, writes ? 1 : 0, kDppWaveShl1, 0xf, 0xf, false) != 0;
+        need1[0] = writes || wl;
+        need1[1] = writes;
+        need1[2] = writes;
+        need1[3] = writes || wr;
+    }
+    const float* pL = inL + woff;
+    const float* pD = inD + woff;
+
+    auto load_raw = [&](int rr) -> Raw {                        // rr in [r0-2, r0+nr+1], clamped + wrapped
+        rr = min(rr, r0 + nr + 1);
+        rr = rr < 0 ? rr + G.H : rr;
+        rr = rr >= G.H ? rr - G.H : rr;
+        Raw w;
+        w.l = stream_load4(pL + (size_t)rr * G.W + col);
+        w.d = stream_load4(pD + (size_t)rr * G.W + col);
+        w.hl = 0.f; w.hd = 0.f;
+        return w;
+    };
+    auto nbrs = [&](const float4& v, float& a, float& c) {
+        if (ROT) { a = dpp_mov<kDppWaveRor1>(0.f, v.w); c = dpp_mov<kDppWaveRol1>(0.f, v.x); }
+        else { a = dpp_mov<kDppWaveShr1>(0.f, v.w); c = dpp_mov<kDppWaveShl1>(0.f, v.x); }   // lanes 0/63: unused
+    };
+    auto to_rows4 = [&](const float4& l, const float4& d, Row4& L, Row4& D) {
+        float a, c;
+        nbrs(l, a, c);
+        L = make_row(l, a, c);
+        nbrs(d, a, c);
+        D = make_row(d, a, c);
+    };
+    unsigned int nq = 0;                                        // queued entries of this wave (uniform)
+    // one row of the map with coefficient set P: (up, mid, down) -> new values; exact mode also queues
+    // the near-tie cells (kind 1 = step 1, 2 = step 2; lrow = row index relative to grid row r0-2)
+    auto row_map = [&](const PhysF32& P, const Row4& upL, const Row4& miL, const Row4& dnL, const Row4& upD,
+                       const Row4& miD, const Row4& dnD, float4& nl, float4& nd, int kind, int lrow, const bool* use) {
+        float ol[4], od[4];
+        bool tie[4];
+        cells4<EXACT>(P, upL, miL, dnL, upD, miD, dnD, ol, od, tie);
+        if (EXACT) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) tie[i] = tie[i] && use[i];
+        }
+        nl = make_float4(ol[0], ol[1], ol[2], ol[3]);
+        nd = make_float4(od[0], od[1], od[2], od[3]);
+        if (EXACT && __ballot(tie[0] || tie[1] || tie[2] || tie[3]) != 0ull) {
+            queue_tie<0>(tie[0], nq, q, (unsigned)G.qcap, kind, lrow, 4 * lane, upL, miL, dnL, upD, miD, dnD, ol, od);
+            queue_tie<1>(tie[1], nq, q, (unsigned)G.qcap, kind, lrow, 4 * lane, upL, miL, dnL, upD, miD, dnD, ol, od);
+            queue_tie<2>(tie[2], nq, q, (unsigned)G.qcap, kind, lrow, 4 * lane, upL, miL, dnL, upD, miD, dnD, ol, od);
+            queue_tie<3>(tie[3], nq, q, (unsigned)G.qcap, kind, lrow, 4 * lane, upL, miL, dnL, upD, miD, dnD, ol, od);
+        }
+    };
+    const bool use2[4] = {writes, writes, writes, writes};
+
+    // windows: IL/ID input rows, SL/SD step-1 rows; slot of row index j (0 = row r0-2) is j % 3
+    Row4 IL[3], ID[3], SL[3], SD[3];
+    {
+        const Raw p0 = load_raw(r0 - 2), p1 = load_raw(r0 - 1), p2 = load_raw(r0);
+        to_rows4(p0.l, p0.d, IL[0], ID[0]);
+        to_rows4(p1.l, p1.d, IL[1], ID[1]);
+        to_rows4(p2.l, p2.d, IL[2], ID[2]);
+    }
+    // iteration j = 1 .. nr+2: step-1 row j (grid row r0-2+j) from input rows j-1, j, j+1; then, from j = 3
+    // on, output row k = j-3 (local row j-1) from step-1 rows j-2, j-1, j
+    auto iter = [&](auto U, int j) {
+        constexpr int u = decltype(U)::value;                  // u == j % 3
+        const Raw nx = load_raw(r0 + j);                       // input row j+2, needed by the NEXT iteration
+        __builtin_amdgcn_sched_barrier(0);
+        float4 l1, d1;
+        row_map(P1, IL[(u + 2) % 3], IL[u], IL[(u + 1) % 3], ID[(u + 2) % 3], ID[u], ID[(u + 1) % 3], l1, d1, 1, j, need1);
+        to_rows4(l1, d1, SL[u], SD[u]);                        // step-1 row j replaces step-1 row j-3
+        if (j >= 3) {
+            float4 l2, d2;
+            row_map(P2, SL[(u + 1) % 3], SL[(u + 2) % 3], SL[u], SD[(u + 1) % 3], SD[(u + 2) % 3], SD[u], l2, d2, 2, j - 1,
+                    use2);
+            if (writes) {
+                const size_t off = woff + (size_t)(r0 + j - 3) * G.W + col;
+                stream_store4(outL + off, l2);
+                stream_store4(outD + off, d2);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        to_rows4(nx.l, nx.d, IL[(u + 2) % 3], ID[(u + 2) % 3]);   // input row j+2 replaces input row j-1
+    };
+    using U0 = std::integral_constant<int, 0>;
+    using U1 = std::integral_constant<int, 1>;
+    using U2 = std::integral_constant<int, 2>;
+    const int jend = nr + 2;
+    int j = 1;
+    for (; j + 2 <= jend; j += 3) {                             // j % 3 == 1 at the top
+        iter(U1{}, j);
+        iter(U2{}, j + 1);
+        iter(U0{}, j + 2);
+    }
+    if (j <= jend) iter(U1{}, j);
+    if (j + 1 <= jend) iter(U2{}, j + 1);
+
+    if (EXACT) {
+        PhysF64 Pa = P64, Pb = P64;
+        Pa.L = La;
+        Pb.L = Lb;
+        // grid coordinates of a local (row, column)
+        auto grid_rc = [&](int lrow, int lc, int& gr, int& gc) {
+            gr = r0 - 2 + lrow;
+            gr = gr < 0 ? gr + G.H : (gr >= G.H ? gr - G.H : gr);
+            gc = c00 + lc;
+            gc = gc < 0 ? gc + G.W : (gc >= G.W ? gc - G.W : gc);
+        };
+        // is local (row, column) an output cell of this wave?
+        auto is_output = [&](int lrow, int lc) -> bool {
+            if (lrow < 2 || lrow > nr + 1) return false;
+            if (ROT) return true;
+            const int ln = lc >> 2;
+            return lc >= 4 && lc < 252 && cs * 248 + 4 * (ln - 1) < G.W;
+        };
+        unsigned int nmm = 0;
+        bool redo = nq > (unsigned)G.qcap;
+        if (!redo) {
+            // F1 + F2 in one sweep over the queue (the entries differ only in the luminosity of their
+            // float64 re-evaluation): a step-1 entry whose float32 value was wrong goes to the mismatch
+            // list; a step-2 entry (payload = float32 step-1 values) patches the output - cells next to a
+            // mismatch are overwritten by F3 below.
+            for (unsigned int base = 0; base < nq; base += 64) {
+                const unsigned int e = base + lane;
+                bool mism = false;
+                unsigned int where = 0;
+                if (e < nq) {
+                    const uint4 e0 = q[e * 3], e1 = q[e * 3 + 1], e2 = q[e * 3 + 2];
+                    const unsigned int w[9] = {unpack_ld(e0.z), unpack_ld(e0.w), unpack_ld(e1.x),
+                                               unpack_ld(e1.y), unpack_ld(e1.z), unpack_ld(e1.w),
+                                               unpack_ld(e2.x), unpack_ld(e2.y), unpack_ld(e2.z)};
+                    PhysF64 Pe = Pa;
+                    Pe.L = e0.x == 1u ? La : Lb;
+                    const NewCoverF64 o = cell_f64_lean(Pe, w);
+                    const unsigned int kl = (unsigned)dw_round3_k(o.nl), kd = (unsigned)dw_round3_k(o.nd);
+                    where = e0.y;
+                    if (e0.x == 1u) {
+                        mism = (kl | (kd << 16)) != unpack_ld(e2.w);
+                    } else {
+                        int gr, gc;
+                        grid_rc((int)(where >> 16), (int)(where & 0xffffu), gr, gc);
+                        const size_t off = woff + (size_t)gr * G.W + gc;
+                        outL[off] = (float)kl;
+                        outD[off] = (float)kd;
+                    }
+                }
+                const unsigned long long mask = __ballot(mism);
+                if (mism) {
+                    const unsigned int slot = nmm + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                                             __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                    if (slot < (unsigned)G.mcap) mm[slot] = where;
+                }
+                nmm += (unsigned)__popcll(mask);
+            }
+            redo = nmm > (unsigned)G.mcap;
+        }
+        if (!redo) {
+            // F3: everything that depends on a step-1 mismatch, entirely in float64 from the inputs.  Two
+            // mismatches per pass: 2 x 25 lanes evaluate step 1 on the 5x5 block around their mismatch
+            // (exchanged through the wave's - by now consumed - queue memory), then 2 x 9 lanes evaluate
+            // step 2 on the 3x3 block of dependents.  One float64 evaluation per lane and stage instead of
+            // ten in a row on nine lanes.
+            unsigned int* s1 = reinterpret_cast<unsigned int*>(q);
+            for (unsigned int m0 = 0; m0 < nmm; m0 += 2) {
+                __builtin_amdgcn_wave_barrier();
+                {
+                    const unsigned int mi = lane / 25u, t = lane - mi * 25u;
+                    if (lane < 50 && m0 + mi < nmm) {
+                        const unsigned int where = mm[m0 + mi];
+                        const int lrow = (int)(where >> 16) + (int)(t / 5u) - 2;
+                        const int lc = (int)(where & 0xffffu) + (int)(t % 5u) - 2;
+                        s1[lane] = exact1_word(pL, pD, G.H, G.W, r0 - 2 + lrow, c00 + lc, Pa);
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                {
+                    const unsigned int mi = lane / 9u, t = lane - mi * 9u;
+                    if (lane < 18 && m0 + mi < nmm) {
+                        const unsigned int where = mm[m0 + mi];
+                        const int dy = (int)(t / 3u) - 1, dx = (int)(t % 3u) - 1;
+                        const int lrow = (int)(where >> 16) + dy;
+                        int lc = (int)(where & 0xffffu) + dx;
+                        if (ROT) lc = (lc + 256) & 255;
+                        if (is_output(lrow, lc)) {
+                            unsigned int w2[9];
+#pragma unroll
+                            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                                for (int e = 0; e < 3; ++e) w2[a * 3 + e] = s1[mi * 25u + (unsigned)((1 + dy + a) * 5 + (1 + dx + e))];
+                            const NewCoverF64 o = cell_f64_lean(Pb, w2);
+                            int gr, gc;
+                            grid_rc(lrow, lc, gr, gc);
+                            const size_t off = woff + (size_t)gr * G.W + gc;
+                            outL[off] = (float)dw_round3_k(o.nl);
+                            outD[off] = (float)dw_round3_k(o.nd);
+                        }
+                    }
+                }
+            }
+        } else {
+            // overflow fallback: every output cell of the strip, two float64 steps from the inputs
+            const int ncol = ROT ? 256 : 248;
+            for (int i = lane; i < nr * ncol; i += 64) {
+                const int lrow = 2 + i / ncol, lc = (ROT ? 0 : 4) + i % ncol;
+                if (!is_output(lrow, lc)) continue;
+                int gr, gc;
+                grid_rc(lrow, lc, gr, gc);
+                float kl, kd;
+                exact2_cell(pL, pD, G.H, G.W, gr, gc, Pa, Pb, kl, kd);
+                const size_t off = woff + (size_t)gr * G.W + gc;
+                outL[off] = kl;
+                outD[off] = kd;
+            }
+        }
+    }
+}
+
+template <bool ROT>
+__global__ __launch_bounds__(256) void step_stream_fused2(const float* __restrict__ inL, const float* __restrict__ inD,
+                                                          float* __restrict__ outL, float* __restrict__ outD,
+                                                          FusedGeom G, PhysF32 P1, PhysF32 P2,
+                                                          unsigned long long* __restrict__ zero_me, int zero_n) {
+    const PhysF64 dummy{};
+    const double zero = 0.0;
+    fused2_body<ROT, false>(inL, inD, outL, outD, G, P1, P2, dummy, zero, zero, zero_me, zero_n);
+}
+
+#ifndef DW_FUSED_EXACT_WAVES
+#define DW_FUSED_EXACT_WAVES 2
+#endif
+struct FusedExactArgs {
+    const float* inL; const float* inD; float* outL; float* outD;
+    FusedGeom G;
+    PhysF32 P1; PhysLumF32 lum2;                                  // step 2 = P1 with these members replaced:
+                                                                  // 15 shared constants instead of 2 x 23 (each
+                                                                  // one occupies an SGPR PAIR as a packed operand)
+    unsigned long long* zero_me; int zero_n;
+    PhysF64 P64; double La; double Lb;                            // cold (see kernarg_struct)
+};
+
+template <bool ROT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DW_FUSED_EXACT_WAVES, DW_FUSED_EXACT_WAVES)))
+void step_stream_fused2_exact(FusedExactArgs A) {
+    const FusedExactArgs& cold = kernarg_struct<FusedExactArgs>();
+    const PhysF32 P2 = with_lum(A.P1, A.lum2);
+    fused2_body<ROT, true>(A.inL, A.inD, A.outL, A.outD, A.G, A.P1, P2, cold.P64, cold.La, cold.Lb, A.zero_me,
+                           A.zero_n);
+}
+
+}  // namespace dw

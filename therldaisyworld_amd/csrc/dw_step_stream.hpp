@@ -1,0 +1,365 @@
+// dw_step_stream.hpp — step_stream_{fast,exact}: the wave-strip streaming step kernel for W >= 256
+// (register window, DPP neighbours, per-wave LDS queue + in-wave float64 fix-up in exact mode).
+#pragma once
+#include "dw_common.hpp"
+
+namespace dw {
+
+// ---------------------------------------------------------------------------------------------
+// step_stream — the hot kernel for wide grids (W >= 256): wave-strip streaming.
+//
+// Every WAVE owns a strip of 256 columns x SR rows of one world and marches down it; a lane owns 4
+// adjacent columns.  Rows are loaded straight into registers with one coalesced 16-byte load per
+// lane and plane, three rows ahead of their use (the data is touched exactly once, so an LDS round
+// trip would be pure overhead — cdna_hip_programming.md §5 "streamed once per block": load straight
+// to VGPRs, deep prefetch, late vmcnt).  The 3x3 stencil is a 3-row register window; horizontal
+// neighbours come from the adjacent lanes with DPP wavefront shifts (v_mov_b32_dpp wave_shr/shl),
+// and the one column to the left / right of the strip arrives either by a wavefront ROTATE (W = 256:
+// the toroidal wrap is inside the wave) or with one extra 4-byte load per row and plane in which
+// lanes 0-31 fetch the left halo column and lanes 32-63 the right one (the DPP "old" operand then
+// drops them into lanes 0 and 63).  No barrier in the loop: waves run independently.
+//
+// Exact mode needs no second kernel: a near-tie cell's 3x3 neighbourhood is already in the window
+// registers, so its 48-byte payload (layout of FixQ) goes into the wave's own LDS queue (slots from
+// ballot + mbcnt, no atomics), and when the strip is finished the same wave re-evaluates its queue
+// in float64, one entry per lane, patches its own stores and corrects its reductions.  A strip
+// whose queue overflows is recomputed whole in float64 at that point.
+//
+// HALO: 0 = W == 256 (rotate), 1 = W a multiple of 256 (every strip full), 2 = general (W % 4 == 0).
+// ---------------------------------------------------------------------------------------------
+// rows per block (= rows in flight per wave while a block is computed) and the occupancy the
+// register allocator plans for; measured on MI355X (profiles/r01_stream_tuning.md)
+#ifndef DW_STREAM_RB_FAST
+#define DW_STREAM_RB_FAST 2
+#endif
+#ifndef DW_STREAM_RB_EXACT
+#define DW_STREAM_RB_EXACT 2
+#endif
+#ifndef DW_STREAM_WAVES_EXACT
+#define DW_STREAM_WAVES_EXACT 3
+#endif
+
+struct StripGeom {
+    int B, H, W;
+    int SR;                   // rows per wave-strip
+    int ncs, nrs;             // column / row strips per world
+    int nstrips;              // B * nrs * ncs
+    int nwg;                  // ceil(nstrips / 4) workgroups of 4 waves
+    int chunk;                // ceil(nwg / 8): workgroups per XCD
+    int qcap;                 // near-tie LDS queue capacity in use (<= kWaveQueueCap; tests shrink it)
+};
+
+// streaming accesses of the hot kernel.  The new planes are not read again within the step, so they
+// are stored non-temporally; non-temporal LOADS were measured slower (-DDW_NT_LOAD keeps the switch).
+typedef float dw_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 stream_load4(const float* p) {
+#ifdef DW_NT_LOAD
+    const dw_f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const dw_f32x4*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+#else
+    return *reinterpret_cast<const float4*>(p);
+#endif
+}
+__device__ __forceinline__ void stream_store4(float* p, const float4& v) {
+#ifndef DW_NO_NT_STORE      // non-temporal stores: measured -1.5 % (fast) / -6 % (exact) on C2
+    dw_f32x4 t;
+    t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+    __builtin_nontemporal_store(t, reinterpret_cast<dw_f32x4*>(p));
+#else
+    *reinterpret_cast<float4*>(p) = v;
+#endif
+}
+
+struct Raw {                  // one row as loaded: own 4 columns of both planes + the halo column values
+    float4 l, d;
+    float hl, hd;             // lanes 0-31: column left of the strip; lanes 32-63: column right of it
+};
+
+constexpr int kDppWaveShl1 = 0x130, kDppWaveRol1 = 0x134, kDppWaveShr1 = 0x138, kDppWaveRor1 = 0x13C;
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float old, float src) {
+#ifdef DW_NO_DPP   // tuning experiment: same data movement through ds_bpermute
+    const int lane = threadIdx.x & 63;
+    if (CTRL == kDppWaveShr1) { const float v = __shfl(src, (lane + 63) & 63, 64); return lane == 0 ? old : v; }
+    if (CTRL == kDppWaveShl1) { const float v = __shfl(src, (lane + 1) & 63, 64); return lane == 63 ? old : v; }
+    if (CTRL == kDppWaveRor1) return __shfl(src, (lane + 63) & 63, 64);
+    return __shfl(src, (lane + 1) & 63, 64);
+#else
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), CTRL, 0xf, 0xf, false));
+#endif
+}
+
+// left / right neighbour values of the lane's 4-column group for one plane
+template <int HALO>
+__device__ __forceinline__ void lr_neighbours(const float4& v, float halo, int lane, int last_lane, float& lnb,
+                                              float& rnb) {
+    if (HALO == 0) {                     // toroidal wrap inside the wave
+        lnb = dpp_mov<kDppWaveRor1>(0.f, v.w);
+        rnb = dpp_mov<kDppWaveRol1>(0.f, v.x);
+    } else if (HALO == 1) {              // lane 0 / lane 63 keep `old` = their halo value
+        lnb = dpp_mov<kDppWaveShr1>(halo, v.w);
+        rnb = dpp_mov<kDppWaveShl1>(halo, v.x);
+    } else {
+        const float left = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(halo), 0));
+        const float right = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(halo), 63));
+        lnb = dpp_mov<kDppWaveShr1>(left, v.w);            // lane 0 keeps `old` = left
+        const float r = dpp_mov<kDppWaveShl1>(right, v.x);  // lane 63 keeps `old` = right
+        rnb = lane == last_lane ? right : r;
+    }
+}
+
+__device__ __forceinline__ Row4 make_row(const float4& v, float lnb, float rnb) {
+    Row4 r;
+    r.x[0] = v.x; r.x[1] = v.y; r.x[2] = v.z; r.x[3] = v.w;
+    r.h2[0] = lnb + v.y;
+    r.h2[1] = v.x + v.z;
+    r.h2[2] = v.y + v.w;
+    r.h2[3] = v.z + rnb;
+    return r;
+}
+
+// the three (light | dark << 16) words of columns i-1, i, i+1 of one window row; the column left of
+// x[0] is h2[0] - x[1] and the one right of x[3] is h2[3] - x[2] (exact: all values are integers)
+// Wave-queue payload word: one (light, dark) pair of per-mille integers in [0, 1000] as the BITS of the
+// float light + 1024*dark (exact: < 2^24) - one fma on the producer side, which runs for every lane of a
+// wave that holds a near-tie cell; the few consumer lanes decode it back to light | dark << 16.
+__device__ __forceinline__ unsigned int pack_ld(float l, float d) { return __float_as_uint(__builtin_fmaf(d, 1024.0f, l)); }
+__device__ __forceinline__ unsigned int unpack_ld(unsigned int bits) {
+    const unsigned int v = (unsigned int)__uint_as_float(bits);
+    return (v & 1023u) | ((v >> 10) << 16);
+}
+
+template <int I>
+__device__ __forceinline__ void pack3(const Row4& L, const Row4& D, unsigned int& w0, unsigned int& w1,
+                                      unsigned int& w2) {
+    const float la = I == 0 ? L.h2[0] - L.x[1] : L.x[I == 0 ? 0 : I - 1];
+    const float da = I == 0 ? D.h2[0] - D.x[1] : D.x[I == 0 ? 0 : I - 1];
+    const float lc = I == 3 ? L.h2[3] - L.x[2] : L.x[I == 3 ? 3 : I + 1];
+    const float dc = I == 3 ? D.h2[3] - D.x[2] : D.x[I == 3 ? 3 : I + 1];
+    w0 = pack_ld(la, da);
+    w1 = pack_ld(L.x[I], D.x[I]);
+    w2 = pack_ld(lc, dc);
+}
+
+constexpr int kWaveQueueCap = 256;          // near-tie entries per wave-strip held in LDS (48 B each)
+
+template <int I>
+__device__ __forceinline__ void queue_tie(bool tie, unsigned int& n, uint4* __restrict__ q, unsigned int cap, int b,
+                                          int row, int colq,
+                                          const Row4& upL, const Row4& miL, const Row4& dnL, const Row4& upD,
+                                          const Row4& miD, const Row4& dnD, const float* ol, const float* od) {
+    const unsigned long long mask = __ballot(tie);
+    if (mask == 0ull) return;                                   // wave-uniform
+    if (tie) {
+        const unsigned int slot = n + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                                __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+        if (slot < cap) {
+            unsigned int u0, u1, u2, m0, m1, m2, d0, d1, d2;
+            pack3<I>(upL, upD, u0, u1, u2);
+            pack3<I>(miL, miD, m0, m1, m2);
+            pack3<I>(dnL, dnD, d0, d1, d2);
+            uint4* dst = q + slot * 3;
+            dst[0] = make_uint4((unsigned)b, ((unsigned)row << 16) | (unsigned)(colq + I), u0, u1);
+            dst[1] = make_uint4(u2, m0, m1, m2);
+            dst[2] = make_uint4(d0, d1, d2, pack_ld(ol[I], od[I]));
+        }
+    }
+    n += (unsigned)__popcll(mask);
+}
+
+template <bool EXACT, int HALO, int RB>
+__device__ __forceinline__ void stream_body(const float* __restrict__ inL, const float* __restrict__ inD,
+                                            float* __restrict__ outL, float* __restrict__ outD, const StripGeom& G,
+                                            const PhysF32& P, const PhysF64& P64, StatsDev* __restrict__ stats,
+                                            unsigned long long* __restrict__ fixups,
+                                            unsigned long long* __restrict__ zero_me, int zero_n) {
+    __shared__ uint4 s_queue[EXACT ? 4 * kWaveQueueCap * 3 : 1];
+    const int bid = blockIdx.x;
+    const int wg = (bid & 7) * G.chunk + (bid >> 3);            // XCD-aware: contiguous run per XCD
+    if (wg >= G.nwg) return;
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    if (wg == 0)
+        for (int i = tid; i < zero_n; i += 256) zero_me[i] = 0ull;
+    uint4* q = s_queue + (EXACT ? wv * kWaveQueueCap * 3 : 0);
+    const int s = wg * 4 + wv;                                  // this wave's strip
+    if (s >= G.nstrips) return;                                 // waves are independent: no barrier anywhere
+    const int spw = G.nrs * G.ncs;
+    const int b = s / spw;
+    const int sw = s - b * spw;
+    const int rs = sw / G.ncs, cs = sw - rs * G.ncs;
+    const int r0 = rs * G.SR, c0 = cs * 256;
+    const int nr = min(G.SR, G.H - r0);
+    const int ncq = min(64, (G.W - c0) >> 2);               // active lanes (4 columns each)
+    const int last_lane = ncq - 1;
+    const bool active = lane < ncq;
+    const size_t woff = (size_t)b * G.H * G.W;
+    const int colq = c0 + 4 * min(lane, last_lane);         // inactive lanes shadow the last active one
+    int hcol = lane < 32 ? c0 - 1 : c0 + 4 * ncq;           // halo column of this lane's half-wave
+    hcol = hcol < 0 ? hcol + G.W : (hcol >= G.W ? hcol - G.W : hcol);
+    const float* pL = inL + woff;
+    const float* pD = inD + woff;
+    const int last_row = r0 + nr;                           // one past the strip: the bottom halo row
+    float acc_max = 0.f, acc_l = 0.f, acc_d = 0.f;
+    unsigned int nq = 0;                                    // entries queued by this wave (uniform)
+
+    auto load_raw = [&](int rr) -> Raw {                    // rr in [r0-1, r0+nr], clamped + wrapped
+        rr = min(rr, last_row);
+        rr = rr < 0 ? rr + G.H : (rr >= G.H ? rr - G.H : rr);
+        const float* rl = pL + (size_t)rr * G.W;
+        const float* rd = pD + (size_t)rr * G.W;
+        Raw w;
+        w.l = stream_load4(rl + colq);
+        w.d = stream_load4(rd + colq);
+        if (HALO != 0) { w.hl = rl[hcol]; w.hd = rd[hcol]; } else { w.hl = 0.f; w.hd = 0.f; }
+        return w;
+    };
+    auto to_rows = [&](const Raw& w, Row4& L, Row4& D) {
+        float a, c;
+        lr_neighbours<HALO>(w.l, w.hl, lane, last_lane, a, c);
+        L = make_row(w.l, a, c);
+        lr_neighbours<HALO>(w.d, w.hd, lane, last_lane, a, c);
+        D = make_row(w.d, a, c);
+    };
+
+    Row4 WL[RB + 2], WD[RB + 2];
+    {
+        Raw p[RB + 2];
+#pragma unroll
+        for (int j = 0; j < RB + 2; ++j) p[j] = load_raw(r0 - 1 + j);
+#pragma unroll
+        for (int j = 0; j < RB + 2; ++j) to_rows(p[j], WL[j], WD[j]);
+    }
+    auto row_math = [&](const Row4& upL, const Row4& miL, const Row4& dnL, const Row4& upD, const Row4& miD,
+                        const Row4& dnD, int k) {
+        float ol[4], od[4];
+        bool tie[4];
+        cells4<EXACT>(P, upL, miL, dnL, upD, miD, dnD, ol, od, tie);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (EXACT) {
+                tie[i] = tie[i] && (HALO != 2 || active);
+                acc_max = fmaxf(acc_max, tie[i] ? 0.f : fmaxf(ol[i], od[i]));
+            } else {
+                acc_max = fmaxf(acc_max, fmaxf(ol[i], od[i]));
+            }
+            acc_l += ol[i]; acc_d += od[i];
+        }
+        if (HALO != 2 || active) {                          // HALO 0/1: every lane owns real columns
+            const size_t off = woff + (size_t)(r0 + k) * G.W + colq;
+            stream_store4(outL + off, make_float4(ol[0], ol[1], ol[2], ol[3]));
+            stream_store4(outD + off, make_float4(od[0], od[1], od[2], od[3]));
+        }
+        if (EXACT) {
+            queue_tie<0>(tie[0], nq, q, (unsigned)G.qcap, b, r0 + k, colq, upL, miL, dnL, upD, miD, dnD, ol, od);
+            queue_tie<1>(tie[1], nq, q, (unsigned)G.qcap, b, r0 + k, colq, upL, miL, dnL, upD, miD, dnD, ol, od);
+            queue_tie<2>(tie[2], nq, q, (unsigned)G.qcap, b, r0 + k, colq, upL, miL, dnL, upD, miD, dnD, ol, od);
+            queue_tie<3>(tie[3], nq, q, (unsigned)G.qcap, b, r0 + k, colq, upL, miL, dnL, upD, miD, dnD, ol, od);
+        }
+    };
+    int k = 0;
+    for (; k + RB <= nr; k += RB) {
+        Raw nx[RB];
+#pragma unroll
+        for (int j = 0; j < RB; ++j) nx[j] = load_raw(r0 + k + RB + 1 + j);
+        __builtin_amdgcn_sched_barrier(0);                  // loads first, then the arithmetic
+#pragma unroll
+        for (int j = 0; j < RB; ++j) row_math(WL[j], WL[j + 1], WL[j + 2], WD[j], WD[j + 1], WD[j + 2], k + j);
+        __builtin_amdgcn_sched_barrier(0);
+        WL[0] = WL[RB]; WD[0] = WD[RB];
+        WL[1] = WL[RB + 1]; WD[1] = WD[RB + 1];
+#pragma unroll
+        for (int j = 0; j < RB; ++j) to_rows(nx[j], WL[2 + j], WD[2 + j]);
+    }
+#pragma unroll
+    for (int j = 0; j < RB - 1; ++j)                        // tail: < RB rows left, already in the window
+        if (k + j < nr) row_math(WL[j], WL[j + 1], WL[j + 2], WD[j], WD[j + 1], WD[j + 2], k + j);
+    if (HALO == 2 && !active) { acc_max = 0.f; acc_l = 0.f; acc_d = 0.f; }
+
+    // ---- exact mode: float64 re-evaluation of this wave's queued near-tie cells ----
+    if (EXACT) {
+        if (nq <= (unsigned)G.qcap) {
+            for (unsigned int e = lane; e < nq; e += 64) {
+                const uint4 e0 = q[e * 3], e1 = q[e * 3 + 1], e2 = q[e * 3 + 2];
+                const unsigned int w[9] = {unpack_ld(e0.z), unpack_ld(e0.w), unpack_ld(e1.x),
+                                           unpack_ld(e1.y), unpack_ld(e1.z), unpack_ld(e1.w),
+                                           unpack_ld(e2.x), unpack_ld(e2.y), unpack_ld(e2.z)};
+                const unsigned int f32v = unpack_ld(e2.w);
+                const NewCoverF64 o = cell_f64_lean(P64, w);
+                const float kl = (float)dw_round3_k(o.nl), kd = (float)dw_round3_k(o.nd);
+                const size_t off = woff + (size_t)(e0.y >> 16) * G.W + (e0.y & 0xffffu);
+                outL[off] = kl;                             // after this wave's own float4 store of the row
+                outD[off] = kd;
+                acc_l += kl - (float)(f32v & 0xffffu);
+                acc_d += kd - (float)(f32v >> 16);
+                acc_max = fmaxf(acc_max, fmaxf(kl, kd));
+            }
+        } else {                                            // queue overflow: the whole strip in float64
+            acc_max = 0.f; acc_l = 0.f; acc_d = 0.f;
+            const int nc = min(256, G.W - c0);
+            for (int i = lane; i < nr * nc; i += 64) {
+                const int r = r0 + i / nc, c = c0 + i % nc;
+                double l9[9], d9[9];
+                gather9(pL, G.H, G.W, r, c, l9);
+                gather9(pD, G.H, G.W, r, c, d9);
+                const CellF64 o = cell_f64(P64, l9, d9);
+                const float kl = (float)dw_round3_k(o.nl), kd = (float)dw_round3_k(o.nd);
+                outL[woff + (size_t)r * G.W + c] = kl;
+                outD[woff + (size_t)r * G.W + c] = kd;
+                acc_l += kl; acc_d += kd;
+                acc_max = fmaxf(acc_max, fmaxf(kl, kd));
+            }
+        }
+    }
+
+    // per-world reductions of this strip: wavefront shuffles, three atomics per strip
+    const float m = wave_max(acc_max);
+    const float sl = wave_sum(acc_l), sd = wave_sum(acc_d);
+    if (lane == 0) {
+        atomicMax(&stats[b].max_k, (unsigned int)m);
+        atomicAdd(&stats[b].sum_l, (unsigned long long)sl);
+        atomicAdd(&stats[b].sum_d, (unsigned long long)sd);
+        if (EXACT && nq) atomicAdd(fixups, (unsigned long long)nq);
+    }
+
+
+}
+
+// Two entry points so that each arithmetic mode gets its own register budget: the float32-only
+// kernel fits 4 waves per SIMD with 2-row blocks; the exact kernel carries the tie test and the
+// fix-up path and is planned for 3 waves per SIMD (<= 168 VGPRs; its 48 KB of LDS queues per
+// workgroup allow 3 workgroups per CU as well).
+template <int HALO>
+__global__ __launch_bounds__(256) void step_stream_fast(const float* __restrict__ inL, const float* __restrict__ inD,
+                                                        float* __restrict__ outL, float* __restrict__ outD,
+                                                        StripGeom G, PhysF32 P, PhysF64 P64,
+                                                        StatsDev* __restrict__ stats,
+                                                        unsigned long long* __restrict__ fixups,
+                                                        unsigned long long* __restrict__ zero_me, int zero_n) {
+    stream_body<false, HALO, DW_STREAM_RB_FAST>(inL, inD, outL, outD, G, P, P64, stats, fixups, zero_me, zero_n);
+}
+
+// The exact kernels' float64 constants are needed only by the rare repair code after the strip loop.
+// Taken as ordinary by-value arguments they are loaded into SGPRs at kernel entry and stay live through
+// the loop, which then runs out of SGPRs (92-190 scalar spills, a v_readlane per use).  So the exact
+// kernels take ONE argument struct, and the cold members are read from the kernarg segment at their use.
+template <typename A>
+__device__ __forceinline__ const A& kernarg_struct() {          // A is the kernel's only argument: offset 0
+    return *reinterpret_cast<const A*>((const void*)__builtin_amdgcn_kernarg_segment_ptr());
+}
+
+struct StreamExactArgs {
+    const float* inL; const float* inD; float* outL; float* outD;
+    StripGeom G; PhysF32 P; StatsDev* stats; unsigned long long* fixups; unsigned long long* zero_me; int zero_n;
+    PhysF64 P64;                                                  // cold
+};
+
+template <int HALO>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DW_STREAM_WAVES_EXACT, DW_STREAM_WAVES_EXACT)))
+void step_stream_exact(StreamExactArgs A) {
+    stream_body<true, HALO, DW_STREAM_RB_EXACT>(A.inL, A.inD, A.outL, A.outD, A.G, A.P,
+                                                kernarg_struct<StreamExactArgs>().P64, A.stats, A.fixups, A.zero_me,
+                                                A.zero_n);
+}
+
+}  // namespace dw

@@ -1,7 +1,7 @@
 """Observation-neighbourhood masks (ref: daisy/nn/functional.py:51-103).
 
 Only the masks live here: the reference's FFT convolution (``ft_convolve``, :12-49) is replaced by
-the LDS-tiled 9-tap toroidal stencil inside the HIP step kernel (csrc/dw_kernels.hpp), and
+the LDS-tiled 9-tap toroidal stencil inside the HIP step kernel (csrc/dw_step_*.hpp), and
 ``glorot`` belongs to the out-of-scope MLP policy.
 """
 import numpy as np
