@@ -72,8 +72,11 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(grid: int, params_obj, budget_s: float = 12.0):
-    """Time the oracle's C restatement on this host: all cores (OpenMP over worlds) and one thread."""
+def cpu_baseline(grid: int, params_obj, budget_s: float = 15.0):
+    """Time the oracle's C restatement on this host: all cores (OpenMP over worlds) on a
+    bounded sample of the workload's grid, one thread on one world of it, and BASELINE configs[0] (C1:
+    1 world, 64x64, 500 steps) exactly, single thread.  Three repeats each, median."""
+    import statistics
     from oracle import c_oracle
     c_oracle.build()
     cores = max(1, min(c_oracle.max_threads(), len(os.sched_getaffinity(0))))
@@ -81,36 +84,40 @@ def cpu_baseline(grid: int, params_obj, budget_s: float = 12.0):
     worlds = 2 * cores
     rng = np.random.RandomState(0)
 
-    def fresh():
-        light = (rng.rand(worlds, g, g) < 0.33) * 0.2 * rng.rand(worlds, g, g)
-        dark = (rng.rand(worlds, g, g) < 0.33) * 0.2 * rng.rand(worlds, g, g)
+    def fresh(n, dim):
+        light = (rng.rand(n, dim, dim) < 0.33) * 0.2 * rng.rand(n, dim, dim)
+        dark = (rng.rand(n, dim, dim) < 0.33) * 0.2 * rng.rand(n, dim, dim)
         return np.ascontiguousarray(light), np.ascontiguousarray(dark)
 
+    def timed(n, dim, steps, repeats=3):
+        rates = []
+        for _ in range(repeats):
+            light, dark = fresh(n, dim)
+            t0 = time.perf_counter()
+            c_oracle.step_n(light, dark, 0.75, 0.75 / 512, steps)
+            rates.append(n * dim * dim * steps / (time.perf_counter() - t0))
+        return statistics.median(rates)
+
     c_oracle.set_threads(cores)
-    light, dark = fresh()
+    light, dark = fresh(worlds, g)
     c_oracle.step_n(light, dark, 0.75, 0.75 / 512, 1)                      # warm-up (thread pool, pages)
     t0 = time.perf_counter()
     c_oracle.step_n(light, dark, 0.75, 0.75 / 512, 2)
     per_step = (time.perf_counter() - t0) / 2
-    steps = int(max(4, min(200, budget_s * 0.7 / max(per_step, 1e-6))))
-    light, dark = fresh()
-    t0 = time.perf_counter()
-    c_oracle.step_n(light, dark, 0.75, 0.75 / 512, steps)
-    dt = time.perf_counter() - t0
-    rate_all = worlds * g * g * steps / dt
-    # single thread on a smaller slice
+    steps = int(max(4, min(200, budget_s * 0.8 / 3 / max(per_step, 1e-6))))
+    rate_all = timed(worlds, g, steps)
     c_oracle.set_threads(1)
-    l1, d1 = light[:1].copy(), dark[:1].copy()
-    s1 = max(2, steps // 4)
-    t0 = time.perf_counter()
-    c_oracle.step_n(l1, d1, 0.75, 0.75 / 512, s1)
-    rate_1 = g * g * s1 / (time.perf_counter() - t0)
+    s1 = max(2, steps // 2)
+    rate_1 = timed(1, g, s1)
+    rate_c1 = timed(1, 64, 500)                                             # BASELINE configs[0], exactly
     c_oracle.set_threads(cores)
     return {
         "value": rate_all, "unit": "cell-updates/s", "cores": cores, "kind": "port",
-        "sample": f"oracle/daisy_oracle.c (float64, reference staging), {worlds} worlds x {g}x{g} x {steps} steps, "
-                  f"OpenMP over worlds on {cores} threads; single thread: {rate_1:.3e} cell-updates/s",
-        "single_thread_value": rate_1,
+        "sample": f"oracle/daisy_oracle.c (float64, reference staging), median of 3: {worlds} worlds x {g}x{g} x "
+                  f"{steps} steps, OpenMP over worlds on {cores} threads; single thread, 1 world x {g}x{g} x {s1} steps: "
+                  f"{rate_1:.3e}; C1 (1 world x 64x64 x 500 steps) single thread: {rate_c1:.3e} cell-updates/s "
+                  f"(the Python reference itself: 1.5-2.2e6 on C1, SURVEY.md 6)",
+        "single_thread_value": rate_1, "c1_single_thread_value": rate_c1,
     }
 
 
