@@ -77,14 +77,20 @@ def test_forward_matches_reference_fixture_g1(amd, golden, tag):
 SHAPES = [
     (3, 8, 8),        # generic kernel, tiny
     (2, 9, 13),       # generic kernel, odd non-square
-    (4, 16, 16),      # generic (W/4 < 16)
-    (3, 64, 64),      # tiled TCQ=16 (C1's shape)
-    (2, 50, 64),      # tiled TCQ=16, partial row tile
-    (2, 96, 128),     # tiled TCQ=32
-    (2, 256, 256),    # tiled TCQ=64 (C2's shape)
-    (1, 70, 320),     # tiled TCQ=64, partial column tile + partial row tile
-    (1, 33, 516),     # W % 4 == 0 but not a multiple of the tile width; H = TR + 1
+    (4, 16, 16),      # packed wave-strip: 16 worlds per wave row, only 4 present
+    (33, 8, 8),       # packed: 32 worlds per wave row, ragged second group (the README sweep's grid)
+    (19, 24, 32),     # packed: 8 worlds per wave row, ragged
+    (3, 64, 64),      # packed: 4 worlds per wave row (C1's shape)
+    (2, 50, 64),      # packed, H < one strip
+    (2, 96, 128),     # packed: 2 worlds per wave row, two row strips
+    (5, 130, 128),    # packed, three row strips, ragged group
+    (2, 40, 96),      # tiled TCQ=16 (W does not divide 256)
+    (2, 50, 192),     # tiled TCQ=32
+    (2, 256, 256),    # wave-strip, wrap inside the wave (C2's shape)
+    (1, 70, 320),     # wave-strip, general halo
+    (1, 33, 516),     # wave-strip, general halo, W % 256 = 4
     (1, 40, 258),     # W % 4 != 0 -> generic
+    (3, 12, 12),      # generic (W = 12 does not divide 256)
     (2, 3, 256),      # streaming kernel, strip shorter than one row block
     (1, 5, 512),      # streaming kernel, dpp-old halo, odd tiny height
     (1, 65, 260),     # streaming kernel, general halo: second strip has a single active lane; H = SR + 1
@@ -598,7 +604,8 @@ def test_c1_trajectory_via_episode_kernel_g2(amd, golden):
 # temporal fusion (two steps per HBM round trip, float32-only mode)
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("B,H,W", [(3, 256, 256), (2, 100, 256), (1, 70, 320), (1, 130, 516), (2, 64, 1024),
-                                   (2, 3, 256), (1, 5, 500), (1, 65, 260)])
+                                   (2, 3, 256), (1, 5, 500), (1, 65, 260),
+                                   (5, 64, 64), (3, 40, 128), (33, 8, 8), (2, 130, 32), (17, 16, 16)])   # packed
 @pytest.mark.parametrize("nsteps", [3, 8, 13])
 @pytest.mark.parametrize("precision", ["fast", "exact"])
 def test_fused_step_pairs_equal_single_steps(amd, monkeypatch, B, H, W, nsteps, precision):
@@ -607,6 +614,7 @@ def test_fused_step_pairs_equal_single_steps(amd, monkeypatch, B, H, W, nsteps, 
     overlapped-strip variants, partial strips, odd counts), the reductions must describe the final
     state and the retained previous state must be the true predecessor."""
     outs = []
+    monkeypatch.setenv("DW_NO_EPISODE_KERNEL", "1")     # small packed worlds: keep dw_step_n on the step kernels
     for fuse in (True, False):
         if fuse:
             monkeypatch.delenv("DW_NO_FUSE", raising=False)
@@ -646,10 +654,12 @@ def test_fused_fast_trajectory_vs_oracle_tolerance(amd):
     eng.close()
 
 
-@pytest.mark.parametrize("B,H,W", [(3, 256, 256), (1, 70, 320), (2, 64, 1024)])
-def test_fused_exact_trajectory_bit_exact_vs_oracle(amd, B, H, W):
+@pytest.mark.parametrize("B,H,W", [(3, 256, 256), (1, 70, 320), (2, 64, 1024),
+                                   (5, 64, 64), (33, 8, 8), (3, 130, 128), (9, 20, 16)])               # packed
+def test_fused_exact_trajectory_bit_exact_vs_oracle(amd, monkeypatch, B, H, W):
     """Exact mode with fused step pairs against the float64 C oracle over 41 steps (20 fused launches +
     the float64 first step from the un-quantised device state): bit-identical planes."""
+    monkeypatch.setenv("DW_NO_EPISODE_KERNEL", "1")
     eng = _engine(amd, B, H, W, 0, "exact")
     assert "step_stream_fused2_exact" in eng.kernel_info()
     eng.init_random(11)
@@ -682,11 +692,14 @@ def test_fused_exact_other_constants_vs_oracle(amd, over, B, H, W):
     eng.close()
 
 
-@pytest.mark.parametrize("B,H,W,nsteps", [(2, 256, 256, 7), (1, 70, 320, 6), (2, 64, 128, 3)])
+@pytest.mark.parametrize("B,H,W,nsteps", [(2, 256, 256, 7), (1, 70, 320, 6), (2, 64, 128, 3), (2, 64, 192, 3),
+                                          (5, 64, 64, 6), (9, 16, 32, 5)])
 @pytest.mark.parametrize("qcap,mcap", [(2, 64), (256, 0), (0, 0)])
 def test_exact_mode_overflow_fallbacks_are_exact(amd, monkeypatch, B, H, W, nsteps, qcap, mcap):
     """Shrink the near-tie queues so that they overflow everywhere: the fallbacks (whole strip / tile
-    recomputed in float64, single-step and fused kernels) must still give the oracle's result."""
+    recomputed in float64, single-step and fused kernels, packed and tiled shapes) must still give the
+    oracle's result."""
+    monkeypatch.setenv("DW_NO_EPISODE_KERNEL", "1")
     monkeypatch.setenv("DW_TEST_QUEUE_CAP", str(qcap))
     monkeypatch.setenv("DW_TEST_MISMATCH_CAP", str(mcap))
     eng = _engine(amd, B, H, W, 0, "exact")

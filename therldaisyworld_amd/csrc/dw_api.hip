@@ -245,14 +245,19 @@ static void select_kernel(dw_handle* h) {
     if (p.width % 4 != 0) return;
     const int Wq = p.width / 4;
     const char* force = std::getenv("DW_KERNEL");               // "tiled" | "stream": A/B experiments
-    if (p.width >= 256 && !(force && std::strcmp(force, "tiled") == 0)) {
+    // packed mode of the wave-strip kernels: narrow worlds whose width divides 256 sit side by side in one
+    // 256-column wave row (256/W worlds per wave)
+    const bool packable = p.width >= 8 && p.width <= 128 && 256 % p.width == 0 && !std::getenv("DW_NO_PACK");
+    if ((p.width >= 256 || packable) && !(force && std::strcmp(force, "tiled") == 0)) {
         h->use_stream = true;
         StripGeom& g = h->sgeom;
         g.B = p.batch; g.H = p.height; g.W = p.width;
         g.SR = p.height < 64 ? p.height : 64;
         g.ncs = (p.width + 255) / 256;
         g.nrs = (p.height + g.SR - 1) / g.SR;
-        g.nstrips = p.batch * g.nrs * g.ncs;
+        g.lpw = packable ? p.width / 4 : 64;
+        g.wpr = packable ? 256 / p.width : 1;
+        g.nstrips = (packable ? (p.batch + g.wpr - 1) / g.wpr : p.batch) * g.nrs * g.ncs;
         g.nwg = (g.nstrips + 3) / 4;
         g.chunk = (g.nwg + 7) / 8;
         g.qcap = kWaveQueueCap;
@@ -269,10 +274,11 @@ static void select_kernel(dw_handle* h) {
         FusedGeom& f = h->fgeom;
         f.B = p.batch; f.H = p.height; f.W = p.width;
         f.SR = g.SR;
-        f.cols_per_strip = p.width == 256 ? 256 : 248;
-        f.ncs = (p.width + f.cols_per_strip - 1) / f.cols_per_strip;
+        f.lpw = g.lpw; f.wpr = g.wpr;
+        f.cols_per_strip = p.width <= 256 ? 256 : 248;
+        f.ncs = packable ? 1 : (p.width + f.cols_per_strip - 1) / f.cols_per_strip;
         f.nrs = (p.height + f.SR - 1) / f.SR;
-        f.nstrips = p.batch * f.nrs * f.ncs;
+        f.nstrips = (packable ? (p.batch + f.wpr - 1) / f.wpr : p.batch) * f.nrs * f.ncs;
         f.nwg = (f.nstrips + 3) / 4;
         f.chunk = (f.nwg + 7) / 8;
         f.qcap = g.qcap;
@@ -390,7 +396,7 @@ static int launch_forward(dw_handle* h, double L) {
         const bool ex = prec == DW_PRECISION_EXACT;
         const StripGeom& g = h->sgeom;
         const dim3 grid((unsigned)g.chunk * 8u);
-        const int halo = p.width == 256 ? 0 : (p.width % 256 == 0 ? 1 : 2);
+        const int halo = p.width < 256 ? 3 : (p.width == 256 ? 0 : (p.width % 256 == 0 ? 1 : 2));
 #define DW_STREAM(K, HL)                                                                                \
     hipLaunchKernelGGL((K<HL>), grid, dim3(256), 0, h->stream, h->L32[in], h->D32[in], h->L32[out],     \
                        h->D32[out], g, P, P64, stats, fixups, zero_me, zero_n)
@@ -399,11 +405,13 @@ static int launch_forward(dw_handle* h, double L) {
                                     zero_n, P64};
             if (halo == 0) hipLaunchKernelGGL((step_stream_exact<0>), grid, dim3(256), 0, h->stream, A);
             else if (halo == 1) hipLaunchKernelGGL((step_stream_exact<1>), grid, dim3(256), 0, h->stream, A);
-            else hipLaunchKernelGGL((step_stream_exact<2>), grid, dim3(256), 0, h->stream, A);
+            else if (halo == 2) hipLaunchKernelGGL((step_stream_exact<2>), grid, dim3(256), 0, h->stream, A);
+            else hipLaunchKernelGGL((step_stream_exact<3>), grid, dim3(256), 0, h->stream, A);
         } else {
             if (halo == 0) DW_STREAM(step_stream_fast, 0);
             else if (halo == 1) DW_STREAM(step_stream_fast, 1);
-            else DW_STREAM(step_stream_fast, 2);
+            else if (halo == 2) DW_STREAM(step_stream_fast, 2);
+            else DW_STREAM(step_stream_fast, 3);
         }
 #undef DW_STREAM
         HIPCHK(hipGetLastError());
@@ -445,14 +453,18 @@ static int launch_forward_fused2(dw_handle* h, double L1, double L2) {
     const int zero_n = (int)(h->stats_bytes / sizeof(unsigned long long));
     const FusedGeom& g = h->fgeom;
     const dim3 grid((unsigned)g.chunk * 8u);
-    const bool rot = p.width == 256;
+    const bool rot = p.width == 256, pack = p.width < 256;
     if (p.precision == DW_PRECISION_EXACT) {
         const FusedExactArgs A{h->L32[in], h->D32[in], h->L32[out], h->D32[out], g, P1, lum_part(P2), zero_me, zero_n,
                                make_f64(p, L1), L1, L2};
-        if (rot) hipLaunchKernelGGL((step_stream_fused2_exact<true>), grid, dim3(256), 0, h->stream, A);
+        if (pack) hipLaunchKernelGGL((step_stream_fused2_exact<true, true>), grid, dim3(256), 0, h->stream, A);
+        else if (rot) hipLaunchKernelGGL((step_stream_fused2_exact<true>), grid, dim3(256), 0, h->stream, A);
         else hipLaunchKernelGGL((step_stream_fused2_exact<false>), grid, dim3(256), 0, h->stream, A);
     } else {
-        if (rot)
+        if (pack)
+            hipLaunchKernelGGL((step_stream_fused2<true, true>), grid, dim3(256), 0, h->stream, h->L32[in], h->D32[in],
+                               h->L32[out], h->D32[out], g, P1, P2, zero_me, zero_n);
+        else if (rot)
             hipLaunchKernelGGL((step_stream_fused2<true>), grid, dim3(256), 0, h->stream, h->L32[in], h->D32[in],
                                h->L32[out], h->D32[out], g, P1, P2, zero_me, zero_n);
         else
@@ -1542,7 +1554,8 @@ int dw_kernel_info(dw_handle* h, char* buf, size_t buflen) {
         snprintf(buf, buflen,
                  "step_stream_%s<halo=%s> wave-strip=%dx256 cells, register window + DPP neighbours, %d-row blocks in "
                  "flight%s, %d strips, grid=%d x 256 threads (4 strips each), XCD-chunked",
-                 prec, p.width == 256 ? "rotate" : (p.width % 256 == 0 ? "dpp-old" : "general"), g.SR,
+                 prec, p.width < 256 ? "packed" : (p.width == 256 ? "rotate" : (p.width % 256 == 0 ? "dpp-old" : "general")),
+                 g.SR,
                  p.precision == DW_PRECISION_EXACT ? DW_STREAM_RB_EXACT : DW_STREAM_RB_FAST,
                  p.precision == DW_PRECISION_EXACT ? ", in-wave float64 fix-up from an LDS queue" : "", g.nstrips,
                  g.chunk * 8);

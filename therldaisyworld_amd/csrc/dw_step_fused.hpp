@@ -26,6 +26,7 @@ struct FusedGeom {
     int nstrips, nwg, chunk;
     int cols_per_strip;       // 256 (ROT) or 248 (OVL)
     int qcap, mcap;           // queue / mismatch-list capacities in use (tests shrink them)
+    int lpw, wpr;             // packed mode (W < 256, W | 256): lanes per world row, worlds per wave row
 };
 
 // float64 step-1 value of grid cell (r, c) (any integers: wrapped onto the torus) from the input planes,
@@ -94,7 +95,10 @@ constexpr int kMismatchCap = 64;            // float32 step-1 mismatches per wav
 // cone was uncertain.  Queue / mismatch-list overflow: the whole strip is recomputed in float64.
 // Fused launches leave the per-world reductions untouched (dw_step_n always ends with a single step,
 // which recomputes them), they only keep the double-buffer protocol.
-template <bool ROT, bool EXACT>
+// PACK (with ROT): narrow worlds (W | 256) side by side in the wave row, as in step_stream<halo=packed>:
+// every lane has its own world, the horizontal wrap is a rotation inside the world's lane group, and a
+// local column lc of the wave row decodes to (world, column) = (lc / W, lc % W).
+template <bool ROT, bool EXACT, bool PACK = false>
 __device__ __forceinline__ void fused2_body(const float* __restrict__ inL, const float* __restrict__ inD,
                                             float* __restrict__ outL, float* __restrict__ outD, const FusedGeom& G,
                                             const PhysF32& P1, const PhysF32& P2, const PhysF64& P64,
@@ -118,14 +122,23 @@ __device__ __forceinline__ void fused2_body(const float* __restrict__ inL, const
     const int rs = sw / G.ncs, cs = sw - rs * G.ncs;
     const int r0 = rs * G.SR;
     const int nr = min(G.SR, G.H - r0);
-    const size_t woff = (size_t)b * G.H * G.W;
+    const int pw = PACK ? lane / G.lpw : 0, pj = PACK ? lane - pw * G.lpw : 0;
+    const int lsrc = PACK ? (pj == 0 ? lane + G.lpw - 1 : lane - 1) : 0;
+    const int rsrc = PACK ? (pj == G.lpw - 1 ? lane - (G.lpw - 1) : lane + 1) : 0;
+    // world base of a local column (PACK: the column's own world; lanes of missing worlds shadow the last)
+    auto world_off = [&](int lc) -> size_t {
+        return (size_t)(PACK ? min(b * G.wpr + (lc >> 2) / G.lpw, G.B - 1) : b) * G.H * G.W;
+    };
+    const size_t woff = world_off(4 * lane);
     const int c00 = ROT ? 0 : cs * 248 - 4;                     // grid column of local column 0 (may be -4)
-    int col = c00 + 4 * lane;
+    int col = PACK ? 4 * pj : c00 + 4 * lane;
     col = col < 0 ? col + G.W : col;
     col = col >= G.W ? col - G.W : col;                         // W >= 256 > 252: one wrap suffices
-    const bool writes = ROT ? true : (lane >= 1 && lane <= 62 && cs * 248 + 4 * (lane - 1) < G.W);
+    const bool writes = PACK ? (b * G.wpr + pw < G.B)
+                             : (ROT ? true : (lane >= 1 && lane <= 62 && cs * 248 + 4 * (lane - 1) < G.W));
     // which of my four step-1 cells feed an output cell of this wave (exact mode: only their ties matter)
     bool need1[4] = {true, true, true, true};
+    if (PACK) { need1[0] = need1[1] = need1[2] = need1[3] = writes; }
     if (EXACT && !ROT) {
         const bool wl = __builtin_amdgcn_update_dpp(0, writes ? 1 : 0, kDppWaveShr1, 0xf, 0xf, false) != 0;
         const bool wr = __builtin_amdgcn_update_dpp(0, writes ? 1 : 0, kDppWaveShl1, 0xf, 0xf, false) != 0;
@@ -148,7 +161,8 @@ __device__ __forceinline__ void fused2_body(const float* __restrict__ inL, const
         return w;
     };
     auto nbrs = [&](const float4& v, float& a, float& c) {
-        if (ROT) { a = dpp_mov<kDppWaveRor1>(0.f, v.w); c = dpp_mov<kDppWaveRol1>(0.f, v.x); }
+        if (PACK) { a = __shfl(v.w, lsrc, 64); c = __shfl(v.x, rsrc, 64); }
+        else if (ROT) { a = dpp_mov<kDppWaveRor1>(0.f, v.w); c = dpp_mov<kDppWaveRol1>(0.f, v.x); }
         else { a = dpp_mov<kDppWaveShr1>(0.f, v.w); c = dpp_mov<kDppWaveShl1>(0.f, v.x); }   // lanes 0/63: unused
     };
     auto to_rows4 = [&](const float4& l, const float4& d, Row4& L, Row4& D) {
@@ -235,9 +249,19 @@ __device__ __forceinline__ void fused2_body(const float* __restrict__ inL, const
             gc = c00 + lc;
             gc = gc < 0 ? gc + G.W : (gc >= G.W ? gc - G.W : gc);
         };
+        // world base and grid coordinates of a local (row, column); false if the column's world is missing
+        auto locate = [&](int lrow, int lc, size_t& wo, int& gr, int& gc) -> bool {
+            grid_rc(lrow, lc, gr, gc);
+            wo = world_off(lc);
+            if (!PACK) return true;
+            const int pwc = (lc >> 2) / G.lpw;
+            gc = lc - pwc * G.W;
+            return b * G.wpr + pwc < G.B;
+        };
         // is local (row, column) an output cell of this wave?
         auto is_output = [&](int lrow, int lc) -> bool {
             if (lrow < 2 || lrow > nr + 1) return false;
+            if (PACK) return b * G.wpr + (lc >> 2) / G.lpw < G.B;
             if (ROT) return true;
             const int ln = lc >> 2;
             return lc >= 4 && lc < 252 && cs * 248 + 4 * (ln - 1) < G.W;
@@ -267,8 +291,9 @@ __device__ __forceinline__ void fused2_body(const float* __restrict__ inL, const
                         mism = (kl | (kd << 16)) != unpack_ld(e2.w);
                     } else {
                         int gr, gc;
-                        grid_rc((int)(where >> 16), (int)(where & 0xffffu), gr, gc);
-                        const size_t off = woff + (size_t)gr * G.W + gc;
+                        size_t wo;
+                        locate((int)(where >> 16), (int)(where & 0xffffu), wo, gr, gc);
+                        const size_t off = wo + (size_t)gr * G.W + gc;
                         outL[off] = (float)kl;
                         outD[off] = (float)kd;
                     }
@@ -297,8 +322,14 @@ __device__ __forceinline__ void fused2_body(const float* __restrict__ inL, const
                     if (lane < 50 && m0 + mi < nmm) {
                         const unsigned int where = mm[m0 + mi];
                         const int lrow = (int)(where >> 16) + (int)(t / 5u) - 2;
-                        const int lc = (int)(where & 0xffffu) + (int)(t % 5u) - 2;
-                        s1[lane] = exact1_word(pL, pD, G.H, G.W, r0 - 2 + lrow, c00 + lc, Pa);
+                        const int lcm = (int)(where & 0xffffu), dx5 = (int)(t % 5u) - 2;
+                        if (PACK) {                         // columns wrap inside the mismatch's own world
+                            const size_t wo = world_off(lcm);
+                            s1[lane] = exact1_word(inL + wo, inD + wo, G.H, G.W, r0 - 2 + lrow,
+                                                   lcm - ((lcm >> 2) / G.lpw) * G.W + dx5, Pa);
+                        } else {
+                            s1[lane] = exact1_word(pL, pD, G.H, G.W, r0 - 2 + lrow, c00 + lcm + dx5, Pa);
+                        }
                     }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -311,7 +342,12 @@ __device__ __forceinline__ void fused2_body(const float* __restrict__ inL, const
                         const int dy = (int)(t / 3u) - 1, dx = (int)(t % 3u) - 1;
                         const int lrow = (int)(where >> 16) + dy;
                         int lc = (int)(where & 0xffffu) + dx;
-                        if (ROT) lc = (lc + 256) & 255;
+                        if (PACK) {
+                            const int lcm = (int)(where & 0xffffu), base = ((lcm >> 2) / G.lpw) * G.W;
+                            lc = base + (lcm - base + dx + G.W) % G.W;
+                        } else if (ROT) {
+                            lc = (lc + 256) & 255;
+                        }
                         if (is_output(lrow, lc)) {
                             unsigned int w2[9];
 #pragma unroll
@@ -320,8 +356,9 @@ __device__ __forceinline__ void fused2_body(const float* __restrict__ inL, const
                                 for (int e = 0; e < 3; ++e) w2[a * 3 + e] = s1[mi * 25u + (unsigned)((1 + dy + a) * 5 + (1 + dx + e))];
                             const NewCoverF64 o = cell_f64_lean(Pb, w2);
                             int gr, gc;
-                            grid_rc(lrow, lc, gr, gc);
-                            const size_t off = woff + (size_t)gr * G.W + gc;
+                            size_t wo;
+                            locate(lrow, lc, wo, gr, gc);
+                            const size_t off = wo + (size_t)gr * G.W + gc;
                             outL[off] = (float)dw_round3_k(o.nl);
                             outD[off] = (float)dw_round3_k(o.nd);
                         }
@@ -335,10 +372,11 @@ __device__ __forceinline__ void fused2_body(const float* __restrict__ inL, const
                 const int lrow = 2 + i / ncol, lc = (ROT ? 0 : 4) + i % ncol;
                 if (!is_output(lrow, lc)) continue;
                 int gr, gc;
-                grid_rc(lrow, lc, gr, gc);
+                size_t wo;
+                locate(lrow, lc, wo, gr, gc);
                 float kl, kd;
-                exact2_cell(pL, pD, G.H, G.W, gr, gc, Pa, Pb, kl, kd);
-                const size_t off = woff + (size_t)gr * G.W + gc;
+                exact2_cell(inL + wo, inD + wo, G.H, G.W, gr, gc, Pa, Pb, kl, kd);
+                const size_t off = wo + (size_t)gr * G.W + gc;
                 outL[off] = kl;
                 outD[off] = kd;
             }
@@ -346,14 +384,14 @@ __device__ __forceinline__ void fused2_body(const float* __restrict__ inL, const
     }
 }
 
-template <bool ROT>
+template <bool ROT, bool PACK = false>
 __global__ __launch_bounds__(256) void step_stream_fused2(const float* __restrict__ inL, const float* __restrict__ inD,
                                                           float* __restrict__ outL, float* __restrict__ outD,
                                                           FusedGeom G, PhysF32 P1, PhysF32 P2,
                                                           unsigned long long* __restrict__ zero_me, int zero_n) {
     const PhysF64 dummy{};
     const double zero = 0.0;
-    fused2_body<ROT, false>(inL, inD, outL, outD, G, P1, P2, dummy, zero, zero, zero_me, zero_n);
+    fused2_body<ROT, false, PACK>(inL, inD, outL, outD, G, P1, P2, dummy, zero, zero, zero_me, zero_n);
 }
 
 #ifndef DW_FUSED_EXACT_WAVES
@@ -369,12 +407,12 @@ struct FusedExactArgs {
     PhysF64 P64; double La; double Lb;                            // cold (see kernarg_struct)
 };
 
-template <bool ROT>
+template <bool ROT, bool PACK = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DW_FUSED_EXACT_WAVES, DW_FUSED_EXACT_WAVES)))
 void step_stream_fused2_exact(FusedExactArgs A) {
     const FusedExactArgs& cold = kernarg_struct<FusedExactArgs>();
     const PhysF32 P2 = with_lum(A.P1, A.lum2);
-    fused2_body<ROT, true>(A.inL, A.inD, A.outL, A.outD, A.G, A.P1, P2, cold.P64, cold.La, cold.Lb, A.zero_me,
+    fused2_body<ROT, true, PACK>(A.inL, A.inD, A.outL, A.outD, A.G, A.P1, P2, cold.P64, cold.La, cold.Lb, A.zero_me,
                            A.zero_n);
 }
 

@@ -47,6 +47,7 @@ struct StripGeom {
     int nwg;                  // ceil(nstrips / 4) workgroups of 4 waves
     int chunk;                // ceil(nwg / 8): workgroups per XCD
     int qcap;                 // near-tie LDS queue capacity in use (<= kWaveQueueCap; tests shrink it)
+    int lpw, wpr;             // packed mode (W < 256, W | 256): lanes per world row (W/4), worlds per wave row
 };
 
 // streaming accesses of the hot kernel.  The new planes are not read again within the step, so they
@@ -91,10 +92,16 @@ __device__ __forceinline__ float dpp_mov(float old, float src) {
 }
 
 // left / right neighbour values of the lane's 4-column group for one plane
+// HALO: 0 = W == 256 (wrap inside the wave), 1 = W % 256 == 0, 2 = any other W >= 256,
+//       3 = packed: W in {8,...,128} divides 256, a wave row holds 256/W worlds side by side and the
+//           toroidal wrap is a rotation inside each world's group of W/4 lanes (ds_bpermute).
 template <int HALO>
 __device__ __forceinline__ void lr_neighbours(const float4& v, float halo, int lane, int last_lane, float& lnb,
-                                              float& rnb) {
-    if (HALO == 0) {                     // toroidal wrap inside the wave
+                                              float& rnb, int lsrc = 0, int rsrc = 0) {
+    if (HALO == 3) {
+        lnb = __shfl(v.w, lsrc, 64);
+        rnb = __shfl(v.x, rsrc, 64);
+    } else if (HALO == 0) {              // toroidal wrap inside the wave
         lnb = dpp_mov<kDppWaveRor1>(0.f, v.w);
         rnb = dpp_mov<kDppWaveRol1>(0.f, v.x);
     } else if (HALO == 1) {              // lane 0 / lane 63 keep `old` = their halo value
@@ -190,11 +197,18 @@ __device__ __forceinline__ void stream_body(const float* __restrict__ inL, const
     const int rs = sw / G.ncs, cs = sw - rs * G.ncs;
     const int r0 = rs * G.SR, c0 = cs * 256;
     const int nr = min(G.SR, G.H - r0);
-    const int ncq = min(64, (G.W - c0) >> 2);               // active lanes (4 columns each)
+    constexpr bool PACK = HALO == 3;
+    // packed mode: `b` is a GROUP of wpr worlds; this lane's world, its column group and the lanes that
+    // hold its left / right neighbour columns (rotation inside the world's lane group)
+    const int pw = PACK ? lane / G.lpw : 0, pj = PACK ? lane - pw * G.lpw : 0;
+    const int world = PACK ? min(b * G.wpr + pw, G.B - 1) : b;      // lanes of missing worlds shadow the last one
+    const int lsrc = PACK ? (pj == 0 ? lane + G.lpw - 1 : lane - 1) : 0;
+    const int rsrc = PACK ? (pj == G.lpw - 1 ? lane - (G.lpw - 1) : lane + 1) : 0;
+    const int ncq = PACK ? 64 : min(64, (G.W - c0) >> 2);   // active lanes (4 columns each)
     const int last_lane = ncq - 1;
-    const bool active = lane < ncq;
-    const size_t woff = (size_t)b * G.H * G.W;
-    const int colq = c0 + 4 * min(lane, last_lane);         // inactive lanes shadow the last active one
+    const bool active = PACK ? (b * G.wpr + pw < G.B) : lane < ncq;
+    const size_t woff = (size_t)world * G.H * G.W;
+    const int colq = PACK ? 4 * pj : c0 + 4 * min(lane, last_lane);   // inactive lanes shadow the last active one
     int hcol = lane < 32 ? c0 - 1 : c0 + 4 * ncq;           // halo column of this lane's half-wave
     hcol = hcol < 0 ? hcol + G.W : (hcol >= G.W ? hcol - G.W : hcol);
     const float* pL = inL + woff;
@@ -211,14 +225,14 @@ __device__ __forceinline__ void stream_body(const float* __restrict__ inL, const
         Raw w;
         w.l = stream_load4(rl + colq);
         w.d = stream_load4(rd + colq);
-        if (HALO != 0) { w.hl = rl[hcol]; w.hd = rd[hcol]; } else { w.hl = 0.f; w.hd = 0.f; }
+        if (HALO == 1 || HALO == 2) { w.hl = rl[hcol]; w.hd = rd[hcol]; } else { w.hl = 0.f; w.hd = 0.f; }
         return w;
     };
     auto to_rows = [&](const Raw& w, Row4& L, Row4& D) {
         float a, c;
-        lr_neighbours<HALO>(w.l, w.hl, lane, last_lane, a, c);
+        lr_neighbours<HALO>(w.l, w.hl, lane, last_lane, a, c, lsrc, rsrc);
         L = make_row(w.l, a, c);
-        lr_neighbours<HALO>(w.d, w.hd, lane, last_lane, a, c);
+        lr_neighbours<HALO>(w.d, w.hd, lane, last_lane, a, c, lsrc, rsrc);
         D = make_row(w.d, a, c);
     };
 
@@ -238,23 +252,23 @@ __device__ __forceinline__ void stream_body(const float* __restrict__ inL, const
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             if (EXACT) {
-                tie[i] = tie[i] && (HALO != 2 || active);
+                tie[i] = tie[i] && (HALO < 2 || active);
                 acc_max = fmaxf(acc_max, tie[i] ? 0.f : fmaxf(ol[i], od[i]));
             } else {
                 acc_max = fmaxf(acc_max, fmaxf(ol[i], od[i]));
             }
             acc_l += ol[i]; acc_d += od[i];
         }
-        if (HALO != 2 || active) {                          // HALO 0/1: every lane owns real columns
+        if (HALO < 2 || active) {                           // HALO 0/1: every lane owns real columns
             const size_t off = woff + (size_t)(r0 + k) * G.W + colq;
             stream_store4(outL + off, make_float4(ol[0], ol[1], ol[2], ol[3]));
             stream_store4(outD + off, make_float4(od[0], od[1], od[2], od[3]));
         }
         if (EXACT) {
-            queue_tie<0>(tie[0], nq, q, (unsigned)G.qcap, b, r0 + k, colq, upL, miL, dnL, upD, miD, dnD, ol, od);
-            queue_tie<1>(tie[1], nq, q, (unsigned)G.qcap, b, r0 + k, colq, upL, miL, dnL, upD, miD, dnD, ol, od);
-            queue_tie<2>(tie[2], nq, q, (unsigned)G.qcap, b, r0 + k, colq, upL, miL, dnL, upD, miD, dnD, ol, od);
-            queue_tie<3>(tie[3], nq, q, (unsigned)G.qcap, b, r0 + k, colq, upL, miL, dnL, upD, miD, dnD, ol, od);
+            queue_tie<0>(tie[0], nq, q, (unsigned)G.qcap, world, r0 + k, colq, upL, miL, dnL, upD, miD, dnD, ol, od);
+            queue_tie<1>(tie[1], nq, q, (unsigned)G.qcap, world, r0 + k, colq, upL, miL, dnL, upD, miD, dnD, ol, od);
+            queue_tie<2>(tie[2], nq, q, (unsigned)G.qcap, world, r0 + k, colq, upL, miL, dnL, upD, miD, dnD, ol, od);
+            queue_tie<3>(tie[3], nq, q, (unsigned)G.qcap, world, r0 + k, colq, upL, miL, dnL, upD, miD, dnD, ol, od);
         }
     };
     int k = 0;
@@ -274,7 +288,7 @@ __device__ __forceinline__ void stream_body(const float* __restrict__ inL, const
 #pragma unroll
     for (int j = 0; j < RB - 1; ++j)                        // tail: < RB rows left, already in the window
         if (k + j < nr) row_math(WL[j], WL[j + 1], WL[j + 2], WD[j], WD[j + 1], WD[j + 2], k + j);
-    if (HALO == 2 && !active) { acc_max = 0.f; acc_l = 0.f; acc_d = 0.f; }
+    if (HALO >= 2 && !active) { acc_max = 0.f; acc_l = 0.f; acc_d = 0.f; }
 
     // ---- exact mode: float64 re-evaluation of this wave's queued near-tie cells ----
     if (EXACT) {
@@ -287,39 +301,76 @@ __device__ __forceinline__ void stream_body(const float* __restrict__ inL, const
                 const unsigned int f32v = unpack_ld(e2.w);
                 const NewCoverF64 o = cell_f64_lean(P64, w);
                 const float kl = (float)dw_round3_k(o.nl), kd = (float)dw_round3_k(o.nd);
-                const size_t off = woff + (size_t)(e0.y >> 16) * G.W + (e0.y & 0xffffu);
+                const size_t off = (size_t)e0.x * G.H * G.W + (size_t)(e0.y >> 16) * G.W + (e0.y & 0xffffu);
                 outL[off] = kl;                             // after this wave's own float4 store of the row
                 outD[off] = kd;
-                acc_l += kl - (float)(f32v & 0xffffu);
-                acc_d += kd - (float)(f32v >> 16);
-                acc_max = fmaxf(acc_max, fmaxf(kl, kd));
+                if (PACK) {                                 // the entry's world is not this lane's: straight to its counters
+                    atomicMax(&stats[e0.x].max_k, (unsigned int)fmaxf(kl, kd));
+                    atomicAdd(&stats[e0.x].sum_l, (unsigned long long)(long long)(kl - (float)(f32v & 0xffffu)));
+                    atomicAdd(&stats[e0.x].sum_d, (unsigned long long)(long long)(kd - (float)(f32v >> 16)));
+                } else {
+                    acc_l += kl - (float)(f32v & 0xffffu);
+                    acc_d += kd - (float)(f32v >> 16);
+                    acc_max = fmaxf(acc_max, fmaxf(kl, kd));
+                }
             }
         } else {                                            // queue overflow: the whole strip in float64
             acc_max = 0.f; acc_l = 0.f; acc_d = 0.f;
-            const int nc = min(256, G.W - c0);
+            const int nc = PACK ? 256 : min(256, G.W - c0);
             for (int i = lane; i < nr * nc; i += 64) {
-                const int r = r0 + i / nc, c = c0 + i % nc;
+                const int r = r0 + i / nc;
+                int c = c0 + i % nc;
+                size_t wo = woff;
+                int wi = b;
+                if (PACK) {                                 // column i % 256 of the wave row -> (world, column)
+                    wi = b * G.wpr + c / G.W;
+                    c -= (c / G.W) * G.W;
+                    if (wi >= G.B) continue;
+                    wo = (size_t)wi * G.H * G.W;
+                }
                 double l9[9], d9[9];
-                gather9(pL, G.H, G.W, r, c, l9);
-                gather9(pD, G.H, G.W, r, c, d9);
+                gather9(inL + wo, G.H, G.W, r, c, l9);
+                gather9(inD + wo, G.H, G.W, r, c, d9);
                 const CellF64 o = cell_f64(P64, l9, d9);
                 const float kl = (float)dw_round3_k(o.nl), kd = (float)dw_round3_k(o.nd);
-                outL[woff + (size_t)r * G.W + c] = kl;
-                outD[woff + (size_t)r * G.W + c] = kd;
-                acc_l += kl; acc_d += kd;
-                acc_max = fmaxf(acc_max, fmaxf(kl, kd));
+                outL[wo + (size_t)r * G.W + c] = kl;
+                outD[wo + (size_t)r * G.W + c] = kd;
+                if (PACK) {
+                    atomicMax(&stats[wi].max_k, (unsigned int)fmaxf(kl, kd));
+                    atomicAdd(&stats[wi].sum_l, (unsigned long long)kl);
+                    atomicAdd(&stats[wi].sum_d, (unsigned long long)kd);
+                } else {
+                    acc_l += kl; acc_d += kd;
+                    acc_max = fmaxf(acc_max, fmaxf(kl, kd));
+                }
             }
         }
     }
 
-    // per-world reductions of this strip: wavefront shuffles, three atomics per strip
-    const float m = wave_max(acc_max);
-    const float sl = wave_sum(acc_l), sd = wave_sum(acc_d);
-    if (lane == 0) {
-        atomicMax(&stats[b].max_k, (unsigned int)m);
-        atomicAdd(&stats[b].sum_l, (unsigned long long)sl);
-        atomicAdd(&stats[b].sum_d, (unsigned long long)sd);
-        if (EXACT && nq) atomicAdd(fixups, (unsigned long long)nq);
+    // per-world reductions of this strip: wavefront shuffles, three atomics per strip (packed mode: per
+    // world of the wave row - a butterfly inside each group of lpw lanes, lpw a power of two)
+    if (PACK) {
+        float m = acc_max, sl = acc_l, sd = acc_d;
+        for (int o = G.lpw >> 1; o > 0; o >>= 1) {
+            m = fmaxf(m, __shfl_xor(m, o, 64));
+            sl += __shfl_xor(sl, o, 64);
+            sd += __shfl_xor(sd, o, 64);
+        }
+        if (pj == 0 && active) {
+            atomicMax(&stats[world].max_k, (unsigned int)m);
+            atomicAdd(&stats[world].sum_l, (unsigned long long)sl);
+            atomicAdd(&stats[world].sum_d, (unsigned long long)sd);
+        }
+        if (EXACT && nq && lane == 0) atomicAdd(fixups, (unsigned long long)nq);
+    } else {
+        const float m = wave_max(acc_max);
+        const float sl = wave_sum(acc_l), sd = wave_sum(acc_d);
+        if (lane == 0) {
+            atomicMax(&stats[b].max_k, (unsigned int)m);
+            atomicAdd(&stats[b].sum_l, (unsigned long long)sl);
+            atomicAdd(&stats[b].sum_d, (unsigned long long)sd);
+            if (EXACT && nq) atomicAdd(fixups, (unsigned long long)nq);
+        }
     }
 
 
