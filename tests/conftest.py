@@ -18,6 +18,8 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "default_pack_threshold: keep the library's default kernel selection for "
+                                       "narrow worlds (the other GPU tests force the packed kernels on small batches)")
 
 
 @pytest.fixture(scope="session")

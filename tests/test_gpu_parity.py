@@ -23,6 +23,15 @@ def amd():
     return t
 
 
+@pytest.fixture(autouse=True)
+def _packed_kernels_for_small_ensembles(request, monkeypatch):
+    """The packed wave-strip kernels normally take over only for ensembles with >= 512 wave-strips (small
+    batches stay on the lower-latency tiled / generic kernels).  The tests run small batches, so they
+    lower the threshold - except those marked `default_pack_threshold`, which cover the small-batch paths."""
+    if "default_pack_threshold" not in request.keywords:
+        monkeypatch.setenv("DW_PACK_MIN_STRIPS", "1")
+
+
 def _engine(amd, B, H, W, N=0, precision="exact", **over):
     from therldaisyworld_amd import _ffi
     p = amd.default_params(B, H, W, N)
@@ -124,6 +133,40 @@ def test_single_step_vs_oracle(amd, B, H, W, precision, L):
     # previous state is retained un-touched
     pl, pd = eng.download_planes(1)
     assert np.array_equal(_k(pl), _k(light)) and np.array_equal(_k(pd), _k(dark))
+    eng.close()
+
+
+@pytest.mark.default_pack_threshold
+@pytest.mark.parametrize("B,H,W,kernel", [(4, 16, 16, "step_generic"), (3, 64, 64, "step_tiled"),
+                                          (2, 96, 128, "step_tiled"), (33, 8, 8, "step_generic")])
+@pytest.mark.parametrize("precision", ["exact", "fast"])
+def test_small_batches_of_narrow_worlds_keep_the_low_latency_kernels(amd, B, H, W, kernel, precision):
+    """Default kernel selection: a handful of narrow worlds is not worth a 64-row serial wave-strip; the
+    tiled / generic kernels answer (and are still checked against the oracle here)."""
+    rng = np.random.RandomState(B + H + W)
+    light, dark = _random_quantised(rng, B, H, W)
+    ref = c_oracle.forward(light, dark, 1.1)
+    eng = _engine(amd, B, H, W, 0, precision)
+    assert kernel in eng.kernel_info()
+    eng.upload_state_f32(light.astype(np.float32), dark.astype(np.float32), quantised=True)
+    eng.step(1.1)
+    gl, gd = eng.download_planes()
+    if precision == "exact":
+        assert np.array_equal(_k(gl), _k(ref[:, 1])) and np.array_equal(_k(gd), _k(ref[:, 2]))
+    else:
+        assert np.abs(_k(gl) - _k(ref[:, 1])).max() <= 1 and np.abs(_k(gd) - _k(ref[:, 2])).max() <= 1
+    s = eng.reduce()
+    assert np.array_equal(s["sum_light_k"], _k(gl).sum(axis=(1, 2)))
+    eng.close()
+
+
+@pytest.mark.default_pack_threshold
+def test_big_ensembles_of_narrow_worlds_take_the_packed_kernels(amd):
+    eng = _engine(amd, 2048, 64, 64, 0, "exact")                # 512 wave-strips of 4 worlds
+    assert "halo=packed" in eng.kernel_info() and "fuses step pairs" in eng.kernel_info()
+    eng.close()
+    eng = _engine(amd, 2044, 64, 64, 0, "exact")                # 511 strips: below the threshold
+    assert "step_tiled" in eng.kernel_info()
     eng.close()
 
 

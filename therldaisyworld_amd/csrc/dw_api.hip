@@ -247,7 +247,13 @@ static void select_kernel(dw_handle* h) {
     const char* force = std::getenv("DW_KERNEL");               // "tiled" | "stream": A/B experiments
     // packed mode of the wave-strip kernels: narrow worlds whose width divides 256 sit side by side in one
     // 256-column wave row (256/W worlds per wave)
-    const bool packable = p.width >= 8 && p.width <= 128 && 256 % p.width == 0 && !std::getenv("DW_NO_PACK");
+    // (only for ensembles with enough wave-strips to occupy the GPU: a lone strip is a serial march down
+    // 64 rows, ~50 us, where the tiled kernel answers in ~9 us; DW_PACK_MIN_STRIPS overrides for tests)
+    int pack_min_strips = 512;
+    if (const char* e = std::getenv("DW_PACK_MIN_STRIPS")) pack_min_strips = std::atoi(e);
+    const bool pack_shape = p.width >= 8 && p.width <= 128 && 256 % p.width == 0 && !std::getenv("DW_NO_PACK");
+    const long pack_strips = pack_shape ? (long)((p.batch + 256 / p.width - 1) / (256 / p.width)) * ((p.height + 63) / 64) : 0;
+    const bool packable = pack_shape && pack_strips >= pack_min_strips;
     if ((p.width >= 256 || packable) && !(force && std::strcmp(force, "tiled") == 0)) {
         h->use_stream = true;
         StripGeom& g = h->sgeom;
@@ -920,8 +926,11 @@ int dw_step_n(dw_handle* h, int32_t nsteps, double* L_io, double dL, double min_
     HIPCHK(hipSetDevice(h->prm.device));
     double L = *L_io;
     int s0 = 0;
-    if (!use_device_actions && nsteps > 1 && h->have_state && h->prm.height * h->prm.width <= 4096) {
-        // small worlds: keep the whole run of steps on the chip (worlds in LDS, one launch per 4096 steps)
+    // Small worlds: keep the whole run of steps on the chip (worlds in LDS, one launch per 4096 steps) -
+    // unless the ensemble is big enough to fill the GPU with wave-strips, where the packed fused kernel is
+    // 1.5-1.8x faster (measured crossover between 2 M and 16 M cells: tools/kbench.py 512 64 / 4096 64).
+    const bool big_packed = h->use_stream && h->allow_fuse && h->prm.width < 256 && h->cells >= ((size_t)1 << 23);
+    if (!use_device_actions && nsteps > 1 && h->have_state && h->prm.height * h->prm.width <= 4096 && !big_packed) {
         if (!episode_kernel_applies(h)) {          // exact mode from an un-quantised state: one ordinary step first
             int rc = launch_forward(h, L);
             if (rc) return rc;
