@@ -258,11 +258,20 @@ static void select_kernel(dw_handle* h) {
         h->use_stream = true;
         StripGeom& g = h->sgeom;
         g.B = p.batch; g.H = p.height; g.W = p.width;
-        g.SR = p.height < 64 ? p.height : 64;
         g.ncs = (p.width + 255) / 256;
-        g.nrs = (p.height + g.SR - 1) / g.SR;
         g.lpw = packable ? p.width / 4 : 64;
         g.wpr = packable ? 256 / p.width : 1;
+        // Strip height: 64 rows (3 % halo re-reads) when that already gives every SIMD two strips; shorter
+        // strips for smaller jobs - a strip is a serial march of ~0.8 us per row, so with few strips the
+        // launch takes as long as ONE strip and most SIMDs idle.  DW_STRIP_ROWS overrides (experiments).
+        {
+            const long groups = (long)(packable ? (p.batch + g.wpr - 1) / g.wpr : p.batch) * g.ncs;
+            int sr = 64;
+            while (sr > 8 && groups * ((p.height + sr - 1) / sr) < 2048) sr >>= 1;    // two strips per SIMD
+            if (const char* e = std::getenv("DW_STRIP_ROWS")) { const int v = std::atoi(e); if (v >= 1) sr = v; }
+            g.SR = p.height < sr ? p.height : sr;
+        }
+        g.nrs = (p.height + g.SR - 1) / g.SR;
         g.nstrips = (packable ? (p.batch + g.wpr - 1) / g.wpr : p.batch) * g.nrs * g.ncs;
         g.nwg = (g.nstrips + 3) / 4;
         g.chunk = (g.nwg + 7) / 8;
