@@ -92,8 +92,11 @@ def main():
                      "cell_updates_per_s_episode": done_at.shape[0] * args.dim * args.dim * steps
                                                    / max(wall - t_reset, 1e-9)})
         if rank == 0:
-            print(f"{name:14s} worlds={done_at.shape[0]:6d} biosphere {done_at.mean():8.3f} +/- {done_at.std():6.3f}"
-                  f"   agents {agents_done_at.mean():8.3f} +/- {agents_done_at.std():6.3f}   {steps} steps in "
+            # mean +/- standard error, as README.md:59-80 reports them
+            se_b = done_at.std() / np.sqrt(done_at.size)
+            se_a = agents_done_at.std() / np.sqrt(agents_done_at.size)
+            print(f"{name:14s} worlds={done_at.shape[0]:6d} biosphere {done_at.mean():8.3f} +/- {se_b:5.3f}"
+                  f"   agents {agents_done_at.mean():8.3f} +/- {se_a:5.3f}   {steps} steps in "
                   f"{wall:.3f} s (reset {t_reset:.3f} s)", flush=True)
     if rank == 0:
         print(json.dumps({"sweep": "README lifespan sweep", "dim": args.dim, "agents": args.agents,
