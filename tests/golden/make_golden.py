@@ -12,6 +12,7 @@ It imports ``/root/reference/daisy`` (never copied into this repo), drives
   G1 forward()      G2 C1 trajectory      G3 scripted agents     G4 Greedy policy
   G5 lifespan sweep G6 ft_convolve pin    G7 no-agent path       G8 collision_mode=1
   G9 constructor / reset RNG order      G10 MLP policy (seeded Glorot)   G11 the shipped trained MLP
+  G12 triangle luminosity ramp (ramp_up_down)
 """
 import os
 import sys
@@ -365,10 +366,46 @@ def g11_trained_mlp():
     save("G11_trained_mlp", **out)
 
 
+def g12_ramp_up_down():
+    """update_L with the triangle ramp (daisy_world_rl.py:463-473: ramp_up_down, ramp_period, ddL): the
+    luminosity schedule over several ramp periods with 2 agents acting, and what a second reset() does to
+    dL / min_L / max_L afterwards."""
+    np.random.seed(99)
+    env = RLDaisyWorld(grid_dimension=8, n_agents=2)
+    env.batch_size = 3
+    env.ramp_up_down = True
+    env.ramp_period = 12
+    env.min_L, env.max_L, env.ddL = 0.9, 1.2, 0.01
+    obs = env.reset()
+    out = {"light0": env.grid[:, 1].copy(), "dark0": env.grid[:, 2].copy(),
+           "agent_indices0": env.agent_indices.copy(), "L0": np.float64(env.L), "dL0": np.float64(env.dL)}
+    actions = np.random.randint(9, size=(60, 3, 2, 1))
+    Ls, dLs, mins, maxs, counts, rewards = [], [], [], [], [], []
+    for t in range(60):
+        obs, reward, done, _ = env.step(actions[t])
+        Ls.append(env.L); dLs.append(env.dL); mins.append(env.min_L); maxs.append(env.max_L)
+        counts.append(env.step_count); rewards.append(reward.copy())
+    out.update(actions=actions, L=np.array(Ls), dL=np.array(dLs), min_L=np.array(mins), max_L=np.array(maxs),
+               step_count=np.array(counts), rewards=np.array(rewards), grid_final=env.grid.copy(),
+               obs_final=obs.copy())
+    obs = env.reset()
+    out.update(reset2_L=np.float64(env.L), reset2_dL=np.float64(env.dL), reset2_min_L=np.float64(env.min_L),
+               reset2_max_L=np.float64(env.max_L), reset2_step_count=np.array(env.step_count),
+               reset2_light=env.grid[:, 1].copy(), reset2_agent_indices=env.agent_indices.copy())
+    a2 = np.random.randint(9, size=(5, 3, 2, 1))
+    L2 = []
+    for t in range(5):
+        env.step(a2[t])
+        L2.append(env.L)
+    out.update(actions2=a2, L2=np.array(L2), grid_final2=env.grid.copy())
+    save("G12_ramp_up_down", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12"]
     fns = {"g1": g1_forward, "g2": g2_c1_trajectory, "g3": g3_agents, "g4": g4_greedy,
            "g5": g5_lifespans, "g6": g6_ft_convolve, "g7": g7_no_agents, "g8": g8_collisions,
-           "g9": g9_ctor_rng_order, "g10": g10_mlp, "g11": g11_trained_mlp}
+           "g9": g9_ctor_rng_order, "g10": g10_mlp, "g11": g11_trained_mlp,
+           "g12": g12_ramp_up_down}
     for w in which:
         fns[w]()

@@ -332,6 +332,17 @@ def test_dropin_ctor_rng_order_g9(amd, golden):
     env.close()
 
 
+def test_dropin_triangle_ramp_g12(amd, golden):
+    """ramp_up_down / ramp_period / ddL assigned after construction, five ramp periods with agents acting,
+    then a second reset(): luminosity schedule, rewards and grids identical to the reference's."""
+    from test_oracle_golden import _g12_checks
+    g = golden("G12_ramp_up_down")
+    np.random.seed(99)
+    env = amd.RLDaisyWorld(grid_dimension=8, n_agents=2)
+    _g12_checks(env, g)
+    env.close()
+
+
 def test_dropin_no_agents_g7(amd, golden):
     g = golden("G7_no_agents")
     np.random.seed(21)

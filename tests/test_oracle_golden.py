@@ -278,3 +278,56 @@ def test_g11_trained_mlp_rollout(golden):
     assert np.array_equal(env.grid, g["grid_final"])
     assert np.array_equal(env.agent_indices, g["agent_indices_final"])
     assert env.L == float(g["L_final"])
+
+
+def _g12_checks(env, g, get=lambda e, k: getattr(e, k), P=None):
+    """Shared by the oracle test here and the drop-in test on the GPU: the G12 protocol on `env`, whose
+    ramp parameters live on `P` (oracle: env.P, drop-in: the environment itself)."""
+    P = env if P is None else P
+    P.ramp_up_down, P.ramp_period = True, 12
+    P.min_L, P.max_L, P.ddL = 0.9, 1.2, 0.01
+    env.batch_size = 3
+    if P is not env:
+        P.batch_size = 3
+    obs = env.reset()
+    assert np.array_equal(env.grid[:, 1], g["light0"]) and np.array_equal(env.agent_indices, g["agent_indices0"])
+    assert env.L == float(g["L0"]) and env.dL == float(g["dL0"])
+    actions = np.random.randint(9, size=(60, 3, 2, 1))
+    assert np.array_equal(actions, g["actions"])
+    for t in range(60):
+        obs, reward, done, _ = env.step(actions[t])
+        assert env.L == g["L"][t] and env.dL == g["dL"][t], t
+        assert P.min_L == g["min_L"][t] and P.max_L == g["max_L"][t] and env.step_count == g["step_count"][t], t
+        assert np.array_equal(reward, g["rewards"][t]), t
+    assert np.array_equal(env.grid, g["grid_final"]) and np.array_equal(obs, g["obs_final"])
+    env.reset()
+    assert env.L == float(g["reset2_L"]) and env.dL == float(g["reset2_dL"]) and env.step_count == 0
+    assert P.min_L == float(g["reset2_min_L"]) and P.max_L == float(g["reset2_max_L"])
+    assert np.array_equal(env.grid[:, 1], g["reset2_light"])
+    assert np.array_equal(env.agent_indices, g["reset2_agent_indices"])
+    a2 = np.random.randint(9, size=(5, 3, 2, 1))
+    for t in range(5):
+        env.step(a2[t])
+        assert env.L == g["L2"][t]
+    assert np.array_equal(env.grid, g["grid_final2"])
+
+
+def test_g12_triangle_ramp(golden):
+    """update_L with ramp_up_down (ref :463-473) over five ramp periods, and the second reset()."""
+    g = golden("G12_ramp_up_down")
+    np.random.seed(99)
+    env = O.OracleDaisyWorld.like_reference_ctor(grid_dimension=8, n_agents=2)
+    _g12_checks(env, g, P=env.P)
+
+
+def test_harness_luminosity_schedule_matches_reference_ramp_g12(golden):
+    """The chunked harnesses precompute the luminosity of the next K steps without touching the
+    environment: same schedule as the reference's update_L, triangle ramp included."""
+    from types import SimpleNamespace
+    from therldaisyworld_amd.harness import _luminosity_schedule
+    g = golden("G12_ramp_up_down")
+    env = SimpleNamespace(L=float(g["L0"]), dL=float(g["dL0"]), step_count=0, min_L=0.9, max_L=1.2, ddL=0.01,
+                          ramp_up_down=True, ramp_period=12)
+    Ls = _luminosity_schedule(env, 61)
+    assert Ls[0] == float(g["L0"]) and Ls[1:] == [float(v) for v in g["L"]]
+    assert (env.L, env.dL, env.step_count, env.min_L, env.max_L) == (float(g["L0"]), float(g["dL0"]), 0, 0.9, 1.2)
