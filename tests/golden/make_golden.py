@@ -12,7 +12,7 @@ It imports ``/root/reference/daisy`` (never copied into this repo), drives
   G1 forward()      G2 C1 trajectory      G3 scripted agents     G4 Greedy policy
   G5 lifespan sweep G6 ft_convolve pin    G7 no-agent path       G8 collision_mode=1
   G9 constructor / reset RNG order      G10 MLP policy (seeded Glorot)   G11 the shipped trained MLP
-  G12 triangle luminosity ramp (ramp_up_down)
+  G12 triangle luminosity ramp (ramp_up_down)      G13 save_config / restore_config round trip
 """
 import os
 import sys
@@ -401,11 +401,42 @@ def g12_ramp_up_down():
     save("G12_ramp_up_down", **out)
 
 
+def g13_config_roundtrip():
+    """save_config / restore_config (daisy_world_rl.py:94-171): a modified environment's 20-key config
+    as the JSON text the reference writes, restored into a fresh environment which then runs 6 steps."""
+    import json
+    import tempfile
+    np.random.seed(5)
+    env = RLDaisyWorld(grid_dimension=8, n_agents=4)
+    env.albedo_light, env.albedo_dark = 0.7, 0.3
+    env.n_agents, env.agent_gamma, env.gamma = 3, 0.04, 0.27
+    env.min_L, env.max_L, env.ramp_period = 0.8, 1.4, 64
+    env.reset()
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "cfg.json")
+        env.save_config(path)
+        text = open(path).read()
+        np.random.seed(6)
+        env2 = RLDaisyWorld(grid_dimension=8, n_agents=4)
+        env2.restore_config(path)
+    env2.batch_size = 4
+    obs = env2.reset()
+    actions = np.random.randint(9, size=(6, 4, 3, 1))
+    for t in range(6):
+        obs, reward, done, _ = env2.step(actions[t])
+    cfg2 = env2.make_config()
+    keys = sorted(cfg2.keys())
+    save("G13_config_roundtrip", config_json=np.array(text), config_keys=np.array(keys),
+         config_after=np.array([float(cfg2[k]) for k in keys]), actions=actions, obs_final=obs.copy(),
+         reward_final=reward.copy(), grid_final=env2.grid.copy(), L_final=np.float64(env2.L),
+         dL_final=np.float64(env2.dL))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
     fns = {"g1": g1_forward, "g2": g2_c1_trajectory, "g3": g3_agents, "g4": g4_greedy,
            "g5": g5_lifespans, "g6": g6_ft_convolve, "g7": g7_no_agents, "g8": g8_collisions,
            "g9": g9_ctor_rng_order, "g10": g10_mlp, "g11": g11_trained_mlp,
-           "g12": g12_ramp_up_down}
+           "g12": g12_ramp_up_down, "g13": g13_config_roundtrip}
     for w in which:
         fns[w]()

@@ -343,6 +343,35 @@ def test_dropin_triangle_ramp_g12(amd, golden):
     env.close()
 
 
+def test_dropin_config_roundtrip_g13(amd, golden, tmp_path):
+    """A config file written by the reference's save_config restores into the drop-in (20 keys, n_agents
+    and albedos among them); the restored environment then reproduces the reference's 6 steps, and its own
+    save_config writes the same JSON object back."""
+    import json
+    g = golden("G13_config_roundtrip")
+    path = tmp_path / "cfg.json"
+    path.write_text(str(g["config_json"]))
+    np.random.seed(6)
+    env = amd.RLDaisyWorld(grid_dimension=8, n_agents=4)
+    env.restore_config(str(path))
+    env.batch_size = 4
+    obs = env.reset()
+    actions = np.random.randint(9, size=(6, 4, 3, 1))
+    assert np.array_equal(actions, g["actions"])
+    for t in range(6):
+        obs, reward, done, _ = env.step(actions[t])
+    assert np.array_equal(obs, g["obs_final"]) and np.array_equal(reward, g["reward_final"])
+    assert np.array_equal(env.grid, g["grid_final"])
+    assert env.L == float(g["L_final"]) and env.dL == float(g["dL_final"])
+    cfg = env.make_config()
+    assert sorted(cfg.keys()) == [str(k) for k in g["config_keys"]]
+    assert [float(cfg[k]) for k in sorted(cfg.keys())] == [float(v) for v in g["config_after"]]
+    again = tmp_path / "again.json"
+    env.save_config(str(again))
+    assert json.loads(again.read_text()) == cfg
+    env.close()
+
+
 def test_dropin_no_agents_g7(amd, golden):
     g = golden("G7_no_agents")
     np.random.seed(21)

@@ -331,3 +331,25 @@ def test_harness_luminosity_schedule_matches_reference_ramp_g12(golden):
     Ls = _luminosity_schedule(env, 61)
     assert Ls[0] == float(g["L0"]) and Ls[1:] == [float(v) for v in g["L"]]
     assert (env.L, env.dL, env.step_count, env.min_L, env.max_L) == (float(g["L0"]), float(g["dL0"]), 0, 0.9, 1.2)
+
+
+def test_g13_config_roundtrip(golden):
+    """The oracle environment fed the reference's saved config reproduces the run after restore_config."""
+    import json
+    g = golden("G13_config_roundtrip")
+    cfg = json.loads(str(g["config_json"]))
+    assert sorted(cfg.keys()) == [str(k) for k in g["config_keys"]] and len(cfg) == 20
+    np.random.seed(6)
+    env = O.OracleDaisyWorld.like_reference_ctor(grid_dimension=8, n_agents=4)
+    for k, v in cfg.items():                      # ref _apply_config :132-152 (dL is overwritten by reset)
+        if k not in ("dL", "initial_L"):
+            setattr(env.P, k, v)
+    env.P.batch_size = 4
+    obs = env.reset()
+    actions = np.random.randint(9, size=(6, 4, 3, 1))
+    assert np.array_equal(actions, g["actions"])
+    for t in range(6):
+        obs, reward, done, _ = env.step(actions[t])
+    assert np.array_equal(obs, g["obs_final"]) and np.array_equal(reward, g["reward_final"])
+    assert np.array_equal(env.grid, g["grid_final"])
+    assert env.L == float(g["L_final"]) and env.dL == float(g["dL_final"])
