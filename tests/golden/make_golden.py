@@ -13,6 +13,7 @@ It imports ``/root/reference/daisy`` (never copied into this repo), drives
   G5 lifespan sweep G6 ft_convolve pin    G7 no-agent path       G8 collision_mode=1
   G9 constructor / reset RNG order      G10 MLP policy (seeded Glorot)   G11 the shipped trained MLP
   G12 triangle luminosity ramp (ramp_up_down)      G13 save_config / restore_config round trip
+  G14 attribute mutations (microclimate off, dt, agent_gamma, q2, temp_optimal, albedos)
 """
 import os
 import sys
@@ -432,11 +433,40 @@ def g13_config_roundtrip():
          dL_final=np.float64(env2.dL))
 
 
+from g14_variants import G14_VARIANTS  # noqa: E402  (pure data, shared with the tests)
+
+
+def g14_attribute_mutations():
+    """The constants callers change on a constructed environment (notebooks: set_use_microclimate, dt,
+    agent_gamma, q2, temp_optimal, albedos ...) followed by reset() and 14 steps with 2 agents."""
+    out = {}
+    for name, spec in G14_VARIANTS.items():
+        np.random.seed(314)
+        env = RLDaisyWorld(grid_dimension=16, n_agents=2)
+        env.batch_size = 2
+        if "call" in spec:
+            getattr(env, spec["call"])(*spec["args"])
+        for k, v in spec.get("attrs", {}).items():
+            setattr(env, k, v)
+        env.min_L, env.max_L, env.ramp_period = 0.8, 1.45, 14
+        obs = env.reset()
+        actions = np.random.randint(9, size=(14, 2, 2, 1))
+        rewards = []
+        for t in range(14):
+            obs, reward, done, _ = env.step(actions[t])
+            rewards.append(reward.copy())
+        out.update({f"{name}_actions": actions, f"{name}_rewards": np.array(rewards), f"{name}_obs": obs.copy(),
+                    f"{name}_grid": env.grid.copy(), f"{name}_q2": np.float64(env.q2),
+                    f"{name}_temp": env.temp.copy(), f"{name}_growth": env.growth.copy()})
+    save("G14_attribute_mutations", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14"]
     fns = {"g1": g1_forward, "g2": g2_c1_trajectory, "g3": g3_agents, "g4": g4_greedy,
            "g5": g5_lifespans, "g6": g6_ft_convolve, "g7": g7_no_agents, "g8": g8_collisions,
            "g9": g9_ctor_rng_order, "g10": g10_mlp, "g11": g11_trained_mlp,
-           "g12": g12_ramp_up_down, "g13": g13_config_roundtrip}
+           "g12": g12_ramp_up_down, "g13": g13_config_roundtrip,
+           "g14": g14_attribute_mutations}
     for w in which:
         fns[w]()

@@ -372,6 +372,19 @@ def test_dropin_config_roundtrip_g13(amd, golden, tmp_path):
     env.close()
 
 
+@pytest.mark.parametrize("name", ["no_microclimate", "slow_time", "other_physics", "wide_albedo"])
+def test_dropin_attribute_mutations_g14(amd, golden, name):
+    """The constants notebooks change on a constructed environment (set_use_microclimate, dt, agent_gamma,
+    q2, temp_optimal, gamma, g, albedos) reach the device: rewards, observations, grid and the temp /
+    growth caches equal the reference's after 14 steps with agents."""
+    from test_oracle_golden import _g14_checks
+    g = golden("G14_attribute_mutations")
+    np.random.seed(314)
+    env = amd.RLDaisyWorld(grid_dimension=16, n_agents=2)
+    _g14_checks(env, g, name)
+    env.close()
+
+
 def test_dropin_no_agents_g7(amd, golden):
     g = golden("G7_no_agents")
     np.random.seed(21)

@@ -353,3 +353,48 @@ def test_g13_config_roundtrip(golden):
     assert np.array_equal(obs, g["obs_final"]) and np.array_equal(reward, g["reward_final"])
     assert np.array_equal(env.grid, g["grid_final"])
     assert env.L == float(g["L_final"]) and env.dL == float(g["dL_final"])
+
+
+def _g14_variants():
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "g14_variants", os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g14_variants.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.G14_VARIANTS
+
+
+def _g14_checks(env, g, name, P=None):
+    """G14 protocol on `env` (oracle: parameters on env.P; drop-in: on the environment itself)."""
+    P = env if P is None else P
+    spec = _g14_variants()[name]
+    P.batch_size = 2
+    env.batch_size = 2
+    if "call" in spec:
+        if hasattr(env, spec["call"]):
+            getattr(env, spec["call"])(*spec["args"])
+        else:                                       # oracle: set_use_microclimate(False) == q2 = 0 (ref :85-92)
+            P.q2 = P.q / 8.0 if spec["args"][0] else 0.0
+    for k, v in spec.get("attrs", {}).items():
+        setattr(P, k, v)
+    P.min_L, P.max_L, P.ramp_period = 0.8, 1.45, 14
+    obs = env.reset()
+    actions = np.random.randint(9, size=(14, 2, 2, 1))
+    assert np.array_equal(actions, g[f"{name}_actions"])
+    for t in range(14):
+        obs, reward, done, _ = env.step(actions[t])
+        assert np.array_equal(reward, g[f"{name}_rewards"][t]), t
+    assert P.q2 == float(g[f"{name}_q2"])
+    assert np.array_equal(obs, g[f"{name}_obs"])
+    assert np.array_equal(env.grid, g[f"{name}_grid"])
+    np.testing.assert_allclose(env.temp, g[f"{name}_temp"], rtol=1e-12, atol=0)
+    np.testing.assert_allclose(env.growth, g[f"{name}_growth"], rtol=1e-9, atol=1e-15)
+
+
+@pytest.mark.parametrize("name", ["no_microclimate", "slow_time", "other_physics", "wide_albedo"])
+def test_g14_attribute_mutations(golden, name):
+    g = golden("G14_attribute_mutations")
+    np.random.seed(314)
+    env = O.OracleDaisyWorld.like_reference_ctor(grid_dimension=16, n_agents=2)
+    _g14_checks(env, g, name, P=env.P)
