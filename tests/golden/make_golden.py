@@ -14,6 +14,7 @@ It imports ``/root/reference/daisy`` (never copied into this repo), drives
   G9 constructor / reset RNG order      G10 MLP policy (seeded Glorot)   G11 the shipped trained MLP
   G12 triangle luminosity ramp (ramp_up_down)      G13 save_config / restore_config round trip
   G14 attribute mutations (microclimate off, dt, agent_gamma, q2, temp_optimal, albedos)
+  G15 direct method calls (get_obs(idx), update_agents, forward(grid), grid assignment, in-place edits)
 """
 import os
 import sys
@@ -461,12 +462,42 @@ def g14_attribute_mutations():
     save("G14_attribute_mutations", **out)
 
 
+def g15_direct_method_calls():
+    """The methods and attribute edits callers use besides reset()/step(): get_obs on caller-supplied
+    positions, update_agents alone, forward(grid) as a function, grid assignment, in-place edits of
+    env.grid and env.agent_states between steps."""
+    np.random.seed(77)
+    env = RLDaisyWorld(grid_dimension=8, n_agents=3)
+    env.batch_size = 2
+    obs = env.reset()
+    out = {"obs0": obs.copy()}
+    idx2 = np.random.randint(8, size=(2, 3, 2))
+    out.update(idx2=idx2, obs_at_idx2=env.get_obs(idx2).copy())
+    a = np.random.randint(5, 9, size=(2, 3, 1))                       # grazing moves
+    env.update_agents(a)
+    out.update(a=a, after_update_indices=env.agent_indices.copy(), after_update_states=env.agent_states.copy(),
+               after_update_grid=env.grid.copy())
+    new = env.forward(env.grid)
+    out.update(forward_new=new.copy(), grid_after_forward_call=env.grid.copy())
+    env.grid = new
+    obs3, r3, d3, _ = env.step(a)
+    out.update(obs3=obs3.copy(), r3=r3.copy(), d3=d3.copy(), grid3=env.grid.copy())
+    env.grid[:, 1] *= 0.5                                              # in-place edits between steps
+    env.agent_states[0, 0, 0] = 0.05
+    env.agent_indices[1, 2] = [3, 4]
+    obs4, r4, d4, _ = env.step(None)
+    out.update(obs4=obs4.copy(), r4=r4.copy(), d4=d4.copy(), grid4=env.grid.copy(),
+               indices4=env.agent_indices.copy(), states4=env.agent_states.copy(), L4=np.float64(env.L))
+    save("G15_direct_method_calls", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14",
+                             "g15"]
     fns = {"g1": g1_forward, "g2": g2_c1_trajectory, "g3": g3_agents, "g4": g4_greedy,
            "g5": g5_lifespans, "g6": g6_ft_convolve, "g7": g7_no_agents, "g8": g8_collisions,
            "g9": g9_ctor_rng_order, "g10": g10_mlp, "g11": g11_trained_mlp,
            "g12": g12_ramp_up_down, "g13": g13_config_roundtrip,
-           "g14": g14_attribute_mutations}
+           "g14": g14_attribute_mutations, "g15": g15_direct_method_calls}
     for w in which:
         fns[w]()

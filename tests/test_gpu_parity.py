@@ -385,6 +385,18 @@ def test_dropin_attribute_mutations_g14(amd, golden, name):
     env.close()
 
 
+def test_dropin_direct_method_calls_g15(amd, golden):
+    """get_obs on caller-supplied positions, update_agents alone, forward(grid) as a function, grid
+    assignment, in-place edits of env.grid / env.agent_states / env.agent_indices between steps: the
+    drop-in's host mirrors notice every one of them, results equal the reference's."""
+    from test_oracle_golden import _g15_checks
+    g = golden("G15_direct_method_calls")
+    np.random.seed(77)
+    env = amd.RLDaisyWorld(grid_dimension=8, n_agents=3)
+    _g15_checks(env, g)
+    env.close()
+
+
 def test_dropin_no_agents_g7(amd, golden):
     g = golden("G7_no_agents")
     np.random.seed(21)

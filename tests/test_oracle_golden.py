@@ -398,3 +398,42 @@ def test_g14_attribute_mutations(golden, name):
     np.random.seed(314)
     env = O.OracleDaisyWorld.like_reference_ctor(grid_dimension=16, n_agents=2)
     _g14_checks(env, g, name, P=env.P)
+
+
+def _g15_checks(env, g, exact_channels=True):
+    """G15 protocol: the calls and edits callers make besides reset()/step()."""
+    env.batch_size = 2
+    if hasattr(env, "P"):
+        env.P.batch_size = 2
+    obs = env.reset()
+    np.testing.assert_allclose(obs, g["obs0"], rtol=1e-12, atol=0)   # un-rounded initial temperatures: FFT noise
+    idx2 = np.random.randint(8, size=(2, 3, 2))
+    assert np.array_equal(idx2, g["idx2"])
+    np.testing.assert_allclose(env.get_obs(idx2), g["obs_at_idx2"], rtol=1e-12, atol=0)
+    a = np.random.randint(5, 9, size=(2, 3, 1))
+    env.update_agents(a)
+    assert np.array_equal(env.agent_indices, g["after_update_indices"])
+    assert np.array_equal(env.agent_states, g["after_update_states"])
+    np.testing.assert_allclose(env.grid, g["after_update_grid"], rtol=1e-12, atol=0)
+    new = env.forward(env.grid)
+    assert np.array_equal(new, g["forward_new"])
+    np.testing.assert_allclose(env.grid, g["grid_after_forward_call"], rtol=1e-12, atol=0)
+    env.grid = new
+    obs3, r3, d3, _ = env.step(a)
+    assert np.array_equal(obs3, g["obs3"]) and np.array_equal(r3, g["r3"]) and np.array_equal(d3, g["d3"])
+    assert np.array_equal(env.grid, g["grid3"])
+    env.grid[:, 1] *= 0.5
+    env.agent_states[0, 0, 0] = 0.05
+    env.agent_indices[1, 2] = [3, 4]
+    obs4, r4, d4, _ = env.step(None)
+    assert np.array_equal(obs4, g["obs4"]) and np.array_equal(r4, g["r4"]) and np.array_equal(d4, g["d4"])
+    assert np.array_equal(env.grid, g["grid4"])
+    assert np.array_equal(env.agent_indices, g["indices4"]) and np.array_equal(env.agent_states, g["states4"])
+    assert env.L == float(g["L4"])
+
+
+def test_g15_direct_method_calls(golden):
+    g = golden("G15_direct_method_calls")
+    np.random.seed(77)
+    env = O.OracleDaisyWorld.like_reference_ctor(grid_dimension=8, n_agents=3)
+    _g15_checks(env, g)

@@ -205,9 +205,12 @@ class RLDaisyWorld:
 
     @grid.setter
     def grid(self, value):
-        value = np.array(value, dtype=np.float64)
-        self._engine.upload_state(value[:, 1], value[:, 2])
-        self._grid_m = None
+        # the reference simply rebinds the attribute: reads return the assigned array (all 7 channels as
+        # given) and later in-place edits of it are edits of the environment's state
+        if not (isinstance(value, np.ndarray) and value.dtype == np.float64):
+            value = np.array(value, dtype=np.float64)
+        self._ensure_engine().upload_state(value[:, 1], value[:, 2])
+        self._grid_m = _Mirror(value)
         self._caches = {}
         self._cache_src = None
 
@@ -340,6 +343,14 @@ class RLDaisyWorld:
     def update_agents(self, action):
         """ref :181-244.  Movement and grazing run on the device; with collision_mode == 1 the
         collision pass (:220-242) follows on the host because it consumes the legacy RNG stream."""
+        grid = self.grid                # the reference mutates self.grid in place (:214-216): only the covers
+        self._update_agents_on_device(action)   # of grazed cells change, other channels keep their stale values
+        light, dark = self._engine.download_planes()
+        grid[:, 1] = light
+        grid[:, 2] = dark
+        self._grid_m = _Mirror(grid)
+
+    def _update_agents_on_device(self, action):
         eng = self._ensure_engine()
         self._sync_to_device()
         eng.update_agents(action)
@@ -400,7 +411,7 @@ class RLDaisyWorld:
         if action is None and self.n_agents:
             action = np.zeros((self.batch_size, self.n_agents, 1))
         if self.collision_mode == 1 and action is not None:
-            self.update_agents(action)                        # device move/graze + host collision pass
+            self._update_agents_on_device(action)             # device move/graze + host collision pass
             action = None
         eng.step(self.L, action)
         self._L_pass = self.L
