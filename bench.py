@@ -196,25 +196,34 @@ def main():
                     eng.run_episode(Ls, _ffi.POLICY_ARGMAX)
                     nsteps -= k
                 return L
-            for _ in range(nsteps):
-                if args.workload == "c5":
-                    # agents 0-3 greedy, 4-7 antigreedy, 8-11 random, 12-15 half-random (one coin per step
-                    # for the batch, as Greedy does): random actions are host-drawn and uploaded, the
-                    # deterministic ones are filled in on the device; nothing is downloaded
-                    a = np.zeros((B, 16), dtype=np.int32)
-                    a[:, 8:12] = rng.randint(9, size=(B, 4))
-                    mode = [_ffi.POLICY_ARGMAX] * 4 + [_ffi.POLICY_ARGMIN] * 4 + [_ffi.POLICY_TABLE] * 4
-                    if rng.rand() > 0.5:
-                        mode += [_ffi.POLICY_ARGMAX] * 4
-                    else:
-                        a[:, 12:16] = rng.randint(9, size=(B, 4))
-                        mode += [_ffi.POLICY_TABLE] * 4
-                    eng.upload_actions(a)
-                    eng.policy_per_agent(mode)
-                else:
-                    eng.policy_greedy(argmin=False)
+            # agent workloads on wide grids (c3, c5): the episode loop stays on the device in chunks
+            # (dw_run_episode without per-step world flags: step pairs in one fused launch, the agents'
+            # in-between step patched in).  c3: every agent greedy.  c5: agents 0-3 greedy, 4-7 antigreedy,
+            # 8-11 random, 12-15 half-random (one coin per step for the batch, as Greedy does); random
+            # actions are drawn on the host into the int8 table, -1 / -2 stand for the greedy / anti-greedy
+            # choice evaluated on the device; nothing is downloaded but the (K,B,N) agent flags.
+            if L == min_L:                                  # first step from the un-quantised state
+                eng.policy_greedy(argmin=False)
                 eng.step_device_actions(L)
                 L = min(max(L + dL, min_L), max_L)
+                nsteps -= 1
+            while nsteps > 0:
+                k = min(nsteps, 64)
+                Ls = []
+                for _ in range(k):
+                    Ls.append(L)
+                    L = min(max(L + dL, min_L), max_L)
+                if args.workload == "c5":
+                    table = np.empty((k, B, 16), dtype=np.int8)
+                    table[:, :, 0:4] = -1
+                    table[:, :, 4:8] = -2
+                    table[:, :, 8:12] = rng.randint(9, size=(k, B, 4))
+                    coin = rng.rand(k) > 0.5
+                    table[:, :, 12:16] = np.where(coin[:, None, None], -1, rng.randint(9, size=(k, B, 4)))
+                    eng.run_episode(Ls, _ffi.POLICY_TABLE, None, table, world_flags=False)
+                else:
+                    eng.run_episode(Ls, _ffi.POLICY_ARGMAX, world_flags=False)
+                nsteps -= k
             return L
 
         L = run(warmup, min_L)
@@ -236,7 +245,9 @@ def main():
         stats = eng.reduce()
         info = eng.kernel_info()
         # dw_step_n runs wide agent-free grids as fused step PAIRS: the dominant kernel's launch = 2 steps
-        spl = 2 if (N == 0 and "fuses step pairs" in info and not os.environ.get("DW_NO_FUSE")) else 1
+        # (agent workloads c3 / c5 too: dw_run_episode pairs the steps and patches the agents' step in)
+        paired = N == 0 or (args.workload in ("c3", "c5") and not os.environ.get("DW_NO_AGENT_FUSE"))
+        spl = 2 if (paired and "fuses step pairs" in info and not os.environ.get("DW_NO_FUSE")) else 1
         res = {"value": cells * steps * n_gpus / elapsed, "ms_per_step": elapsed / steps * 1e3,
                "kernel_ms": kernel_ms, "achieved": achieved, "frac": achieved / HBM_PEAK_GBS,
                "fixups": eng.last_fixup_count(), "kernel": info, "stats": stats, "steps_per_launch": spl}

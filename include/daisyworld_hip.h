@@ -278,9 +278,13 @@ int dw_lifespan_download(dw_handle* h, int32_t* done_at /* [B] */, int32_t* agen
  *                   DW_POLICY_ZEROS (ref step(None): action 0), DW_POLICY_TABLE (all actions given)
  *   use_table[K]    per step: 1 = this step's actions come from `table` (Greedy's epsilon branch,
  *                   drawn by the caller from the legacy NumPy stream); may be NULL (all 0)
- *   table[K][B][N]  int8 action codes; may be NULL if never used
+ *   table[K][B][N]  int8 codes: 0..8 an action, -1 / -2 the greedy / anti-greedy choice of that agent at
+ *                   that step (mixed-policy ensembles, BASELINE configs[4]); may be NULL if never used
  *   world_alive[K][B], agent_ok[K][B][N]   per-step flags out: max cover > threshold_k/1000, and
  *                   reward >= 0.1 (what the harness adds to done_at / agents_done_at)
+ * world_alive may be NULL: without per-step world reductions wide grids (and big ensembles of narrow
+ * ones) run step PAIRS as one fused launch, with the agents' step in between recomputed around the
+ * agents and patched into the result (csrc/dw_agents_fused.hpp) - same results, bit for bit.
  * Needs a quantised current state in exact mode (take the first step of an episode with dw_step).
  * Afterwards the handle is exactly as after K calls of dw_step (previous state retained). */
 enum { DW_POLICY_ZEROS = 2, DW_POLICY_TABLE = 3 };

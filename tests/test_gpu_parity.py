@@ -658,6 +658,46 @@ def test_run_episode_matches_stepwise_engine(amd, B, H, W):
     assert np.array_equal(a[6], b[6]) and np.array_equal(a[7], b[7])
 
 
+@pytest.mark.parametrize("B,H,W,N", [(3, 64, 256, 5), (2, 130, 520, 3), (6, 32, 64, 4), (33, 8, 8, 6), (1, 70, 320, 16)])
+@pytest.mark.parametrize("precision", ["exact", "fast"])
+@pytest.mark.parametrize("policy", ["argmax", "argmin_with_random_steps", "mixed_table"])
+def test_agent_step_pairs_equal_single_steps(amd, monkeypatch, B, H, W, N, precision, policy):
+    """dw_run_episode without per-step world flags runs step PAIRS as one fused launch and patches the
+    agents' in-between step in (policy from recomputed step-1 values, grazing in agent order, 3x3 blocks
+    around the grazed cells recomputed): planes, agents, per-step agent flags, reductions, observations and
+    the retained previous state equal K ordinary steps bit for bit - crowded 8x8 worlds (agents meet on
+    cells), packed and wide grids, greedy / anti-greedy / random / per-agent mixes."""
+    from therldaisyworld_amd import _ffi
+    K = 11
+    rng = np.random.RandomState(B * 7 + N)
+    use, table, mode = None, None, _ffi.POLICY_ARGMAX
+    if policy == "argmin_with_random_steps":
+        mode = _ffi.POLICY_ARGMIN
+        use = (rng.rand(K) < 0.4).astype(np.uint8)
+        table = rng.randint(9, size=(K, B, N)).astype(np.int8)
+    elif policy == "mixed_table":                         # per agent and step: action, greedy (-1) or anti-greedy (-2)
+        mode = _ffi.POLICY_TABLE
+        table = rng.randint(-2, 9, size=(K, B, N)).astype(np.int8)
+    outs = []
+    for pairs in (True, False):
+        if pairs:
+            monkeypatch.delenv("DW_NO_AGENT_FUSE", raising=False)
+        else:
+            monkeypatch.setenv("DW_NO_AGENT_FUSE", "1")
+        eng = _engine(amd, B, H, W, N, precision)
+        eng.init_random(91)
+        L, dL = 0.95, 0.012
+        eng.step(L, np.zeros((B, N, 1), dtype=int))         # quantise the state
+        Ls = [L + (i + 1) * dL for i in range(K)]
+        alive, ok = eng.run_episode(Ls, mode, use, table, world_flags=False)
+        assert alive is None
+        outs.append((ok, *eng.download_planes(), *eng.download_planes(1), *eng.download_agents(),
+                     eng.reduce().tobytes(), eng.download_grid(), eng.get_obs()))
+        eng.close()
+    for x, y in zip(*outs):
+        assert np.array_equal(x, y)
+
+
 @pytest.mark.parametrize("B,H,W,N", [(4, 16, 16, 3), (2, 64, 256, 2)])
 def test_snapshot_restore_replays_identically(amd, B, H, W, N):
     """dw_snapshot_save / dw_snapshot_restore: after a restore the same steps give the same state

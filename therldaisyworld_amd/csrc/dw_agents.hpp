@@ -126,7 +126,8 @@ __global__ void observe(const PrevT* __restrict__ pL, const PrevT* __restrict__ 
 // the buffer (e.g. host-drawn random actions uploaded earlier) — mixed-policy ensembles (BASELINE C5).
 __global__ void policy_greedy(const float* __restrict__ cL, const float* __restrict__ cD,
                               const int* __restrict__ idx, int B, int N, int H, int W, int mask,
-                              int argmin, const int* __restrict__ agent_mode, int* __restrict__ action) {
+                              int argmin, const int* __restrict__ agent_mode, int* __restrict__ action,
+                              int codes = 0) {
     const int an = blockIdx.x * blockDim.x + threadIdx.x;
     if (an >= B * N) return;
     const int b = an / N;
@@ -134,6 +135,11 @@ __global__ void policy_greedy(const float* __restrict__ cL, const float* __restr
         const int m = agent_mode[an - b * N];
         if (m == 2) return;
         argmin = m == 1;
+    }
+    if (codes) {                         // `action` holds table codes: >= 0 an action (kept), -1 argmax, -2 argmin
+        const int a = action[an];
+        if (a >= 0) return;
+        argmin = a == -2;
     }
     const int ar = idx[(size_t)an * 2], ac = idx[(size_t)an * 2 + 1];
     const size_t woff = (size_t)b * H * W;
@@ -228,6 +234,12 @@ __global__ void episode_flags(const StatsDev* __restrict__ stats, const double* 
         const double rw = s * (s > 0.0 ? 1.0 : 0.0);
         agent_ok[i] = rw < 0.1 ? 0 : 1;
     }
+}
+__global__ void agent_flags(const double* __restrict__ st, int n, unsigned char* __restrict__ agent_ok) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double s = st[i];
+    agent_ok[i] = (s * (s > 0.0 ? 1.0 : 0.0)) < 0.1 ? 0 : 1;
 }
 __global__ void actions_from_table(const signed char* __restrict__ table, int n, int* __restrict__ action) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

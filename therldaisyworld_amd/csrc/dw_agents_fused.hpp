@@ -1,0 +1,187 @@
+// dw_agents_fused.hpp — agents between the two steps of a fused launch.
+//
+// With agents the reference's episode is  policy_t, graze_t, forward_t, policy_{t+1}, graze_{t+1},
+// forward_{t+1}, ...: the agents act on the grid between ANY two physics passes, so step pairs cannot
+// simply share an HBM round trip.  But N agents touch N cells.  The pair (t, t+1) is run as
+//
+//     policy_t, graze_t            (as always, on the state S0 in memory  ->  S0')
+//     step_stream_fused2           S2 = F(F(S0'))  - the grazing of step t+1 ignored
+//     agents_lookahead_patch       this kernel, one wave per world:
+//         A  recompute S1 = F(S0') on the 5 cells each agent can see / reach (from S0', which the fused
+//            launch left intact in the other buffer) and evaluate policy_{t+1} (ref Greedy.__call__,
+//            agents/greedy.py:14-36, or the caller's table)
+//         B  graze_{t+1} (ref update_agents :181-244) for the world's agents in order, on those S1 values
+//            (a cell grazed by an earlier agent of the same step reads 0), recording the grazed cells
+//         C  recompute S2 on the 3x3 blocks around the grazed cells from S1' (= S1 with the grazed cells
+//            zeroed, each S1 value again from S0') and overwrite those <= 9 N cells of the output planes.
+//
+// Exact mode evaluates A and C in float64 (what the exact kernels' results equal by construction); the
+// float32-only mode evaluates them with the same float32 algebra as the step kernels (the one-cell
+// instantiation of growth_t: bit-identical to the packed form), so the pair equals two ordinary steps
+// bit for bit in both modes.  Inputs are quantised states (integer per-mille values).
+#pragma once
+#include "dw_step_fused.hpp"
+
+namespace dw {
+
+constexpr int kLookaheadMaxAgents = 64;      // agents per world handled by one wave (lane n = agent n)
+
+// float32 step value of grid cell (r, c) (any integers: wrapped onto the torus) of a quantised state, as
+// the step kernels compute it, packed light | dark << 16
+__device__ inline unsigned int fast1_word(const float* __restrict__ pL, const float* __restrict__ pD, int H, int W, int r,
+                                          int c, const PhysF32& P) {
+    const int rr = ((r % H) + H) % H, cc = ((c % W) + W) % W;
+    const int ru = rr == 0 ? H - 1 : rr - 1, rd = rr == H - 1 ? 0 : rr + 1;
+    const int cl = cc == 0 ? W - 1 : cc - 1, cr = cc == W - 1 ? 0 : cc + 1;
+    const float* uL = pL + (size_t)ru * W; const float* mL = pL + (size_t)rr * W; const float* dL = pL + (size_t)rd * W;
+    const float* uD = pD + (size_t)ru * W; const float* mD = pD + (size_t)rr * W; const float* dD = pD + (size_t)rd * W;
+    // same association as cells4 (exact anyway: the inputs are integers)
+    const float El = (mL[cl] + mL[cr]) + (uL[cc] + dL[cc]);
+    const float Cl = (uL[cl] + uL[cr]) + (dL[cl] + dL[cr]);
+    const float Ed = (mD[cl] + mD[cr]) + (uD[cc] + dD[cc]);
+    const float Cd = (uD[cl] + uD[cr]) + (dD[cl] + dD[cr]);
+    const GrowthF32 g = growth_t<false, float>(P, mL[cc], mD[cc], El, Cl, Ed, Cd);
+    return (unsigned int)finish_fast(mL[cc], g.gql) | ((unsigned int)finish_fast(mD[cc], g.gqd) << 16);
+}
+
+// the same map on nine already-evaluated (light | dark << 16) words of a 3x3 block, row-major
+__device__ inline unsigned int fast_word_from9(const unsigned int* w, const PhysF32& P) {
+    float l[9], d[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { l[i] = (float)(w[i] & 0xffffu); d[i] = (float)(w[i] >> 16); }
+    const float El = (l[3] + l[5]) + (l[1] + l[7]);
+    const float Cl = (l[0] + l[2]) + (l[6] + l[8]);
+    const float Ed = (d[3] + d[5]) + (d[1] + d[7]);
+    const float Cd = (d[0] + d[2]) + (d[6] + d[8]);
+    const GrowthF32 g = growth_t<false, float>(P, l[4], d[4], El, Cl, Ed, Cd);
+    return (unsigned int)finish_fast(l[4], g.gql) | ((unsigned int)finish_fast(d[4], g.gqd) << 16);
+}
+
+struct LookaheadArgs {
+    const float* inL; const float* inD;          // S0': the state the fused launch read
+    float* outL; float* outD;                    // S2 written by the fused launch, patched here
+    int* idx; double* st;                        // agents after step t, updated to step t+1
+    const signed char* code;                     // [B][N] for step t+1: 0..8 action, -1 greedy argmax, -2 argmin
+    unsigned char* agent_ok;                     // [B][N] reward >= 0.1 after step t+1, or null
+    int B, N, H, W, mask;
+    double agent_gamma;
+    PhysF32 P1, P2;                              // float32 coefficient sets of steps t, t+1 (fast mode)
+    PhysF64 P64; double La, Lb;                  // float64 constants and the two luminosities (exact mode)
+};
+
+template <bool EXACT>
+__global__ __launch_bounds__(64) void agents_lookahead_patch(LookaheadArgs A) {
+    __shared__ unsigned int s_s1[kLookaheadMaxAgents][5];      // S1 at centre, (r,c-1), (r-1,c), (r+1,c), (r,c+1)
+    __shared__ int s_act[kLookaheadMaxAgents];
+    __shared__ int s_gr[kLookaheadMaxAgents], s_gc[kLookaheadMaxAgents];
+    __shared__ int s_ng;
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int N = A.N, H = A.H, W = A.W;
+    const size_t woff = (size_t)b * H * W;
+    const float* pL = A.inL + woff;
+    const float* pD = A.inD + woff;
+    PhysF64 Pa = A.P64, Pb = A.P64;
+    Pa.L = A.La;
+    Pb.L = A.Lb;
+    auto step1 = [&](int r, int c) -> unsigned int {
+        return EXACT ? exact1_word(pL, pD, H, W, r, c, Pa) : fast1_word(pL, pD, H, W, r, c, A.P1);
+    };
+
+    // ---- A: what each agent sees after forward_t, and its action for step t+1 ----
+    if (lane < N) {
+        const int an = b * N + lane;
+        const int ar = A.idx[(size_t)an * 2], ac = A.idx[(size_t)an * 2 + 1];
+        const int dr[5] = {0, 0, -1, 1, 0}, dc[5] = {0, -1, 0, 0, 1};      // centre, then Greedy's order 3,1,7,5
+        unsigned int v[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) { v[i] = step1(ar + dr[i], ac + dc[i]); s_s1[lane][i] = v[i]; }
+        int a = (int)A.code[an];
+        if (a < 0) {                                                       // ref Greedy.__call__ :18-30
+            const bool argmin = a == -2;
+            const int cand[4] = {3, 1, 7, 5};
+            int best = 0;
+            double bestv = 0.0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                double val = 0.0;
+                if ((A.mask >> cand[i]) & 1)
+                    val = (double)(float)(v[i + 1] & 0xffffu) / 1000.0 + (double)(float)(v[i + 1] >> 16) / 1000.0;
+                if (i == 0 || (argmin ? val < bestv : val > bestv)) { best = i; bestv = val; }
+            }
+            a = 4 + best;
+        }
+        s_act[lane] = a;
+    }
+    if (lane == 0) s_ng = 0;
+    __syncthreads();
+
+    // ---- B: update_agents of step t+1 (ref :181-244), agents in order ----
+    if (lane == 0) {
+        for (int n = 0; n < N; ++n) A.st[(size_t)b * N + n] -= A.agent_gamma;                  // ref :184
+        int ng = 0;
+        for (int n = 0; n < N; ++n) {
+            double s = A.st[(size_t)b * N + n];
+            if (s > 0.0) {                                                                  // ref :189
+                const int a = s_act[n];
+                int r = A.idx[((size_t)b * N + n) * 2], c = A.idx[((size_t)b * N + n) * 2 + 1];
+                int which = 0;                                                              // slot of s_s1 it lands on
+                if (a != 8) {                                                               // ref :191-206
+                    const int m = ((a % 4) + 4) % 4;
+                    if (m == 0) { c -= 1; which = 1; } else if (m == 1) { r -= 1; which = 2; }
+                    else if (m == 2) { r += 1; which = 3; } else { c += 1; which = 4; }
+                }
+                r = ((r % H) + H) % H;                                                      // ref :208
+                c = ((c % W) + W) % W;
+                A.idx[((size_t)b * N + n) * 2] = r;
+                A.idx[((size_t)b * N + n) * 2 + 1] = c;
+                if (a > 4) {                                                                // ref :210-216
+                    bool eaten = false;                       // an earlier agent of this step emptied the cell
+                    for (int g = 0; g < ng; ++g) eaten = eaten || (s_gr[g] == r && s_gc[g] == c);
+                    if (!eaten) {
+                        const unsigned int w = s_s1[n][which];
+                        s += (double)(float)(w & 0xffffu) / 1000.0 + (double)(float)(w >> 16) / 1000.0;
+                        s_gr[ng] = r; s_gc[ng] = c; ++ng;
+                    }
+                    A.st[(size_t)b * N + n] = s;
+                }
+            }
+        }
+        for (int n = 0; n < N; ++n) {                                                        // ref :244
+            const double s = A.st[(size_t)b * N + n];
+            const double cl = s < 0.0 ? 0.0 : (s > 1.0 ? 1.0 : s);
+            A.st[(size_t)b * N + n] = cl;
+            if (A.agent_ok) A.agent_ok[(size_t)b * N + n] = (cl * (cl > 0.0 ? 1.0 : 0.0)) < 0.1 ? 0 : 1;
+        }
+        s_ng = ng;
+    }
+    __syncthreads();
+
+    // ---- C: S2 on the 3x3 blocks around the grazed cells, from S1' ----
+    const int ng = s_ng;
+    for (int p = lane; p < ng * 9; p += 64) {
+        const int g = p / 9, t = p - g * 9;
+        const int xr = ((s_gr[g] + t / 3 - 1) % H + H) % H, xc = ((s_gc[g] + t % 3 - 1) % W + W) % W;
+        unsigned int w2[9];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int e = 0; e < 3; ++e) {
+                const int yr = ((xr + a - 1) % H + H) % H, yc = ((xc + e - 1) % W + W) % W;
+                bool grazed = false;
+                for (int k = 0; k < ng; ++k) grazed = grazed || (s_gr[k] == yr && s_gc[k] == yc);
+                w2[a * 3 + e] = grazed ? 0u : step1(yr, yc);
+            }
+        unsigned int out;
+        if (EXACT) {
+            const NewCoverF64 o = cell_f64_lean(Pb, w2);
+            out = (unsigned int)dw_round3_k(o.nl) | ((unsigned int)dw_round3_k(o.nd) << 16);
+        } else {
+            out = fast_word_from9(w2, A.P2);
+        }
+        const size_t off = woff + (size_t)xr * W + xc;
+        A.outL[off] = (float)(out & 0xffffu);
+        A.outD[off] = (float)(out >> 16);
+    }
+}
+
+}  // namespace dw

@@ -1357,7 +1357,8 @@ static int run_episode_stepwise(dw_handle* h, int32_t nsteps, const double* L_sc
     const int N = p.n_agents, B = p.batch;
     const size_t K = (size_t)nsteps, bn = (size_t)B * N;
     auto up = [](size_t v) { return (v + 255) / 256 * 256; };
-    const size_t o_tab = 0, o_wa = up(o_tab + K * bn), o_ok = up(o_wa + K * B), total = up(o_ok + K * bn) + 256;
+    const size_t o_tab = 0, o_wa = up(o_tab + K * bn), o_ok = up(o_wa + K * B), o_code = up(o_ok + K * bn);
+    const size_t total = up(o_code + bn) + 256;
     if (h->ep_bytes < total) {
         if (h->ep_buf) HIPCHK(hipFree(h->ep_buf));
         h->ep_buf = nullptr; h->ep_bytes = 0;
@@ -1366,12 +1367,23 @@ static int run_episode_stepwise(dw_handle* h, int32_t nsteps, const double* L_sc
     }
     if (table && bn) HIPCHK(hipMemcpyAsync(h->ep_buf + o_tab, table, K * bn, hipMemcpyHostToDevice, h->stream));
     const int nflag = B > (int)bn ? B : (int)bn;
+    // Step pairs on wide grids (dw_agents_fused.hpp): policy_t, graze_t, ONE fused launch for forward_t and
+    // forward_{t+1}, then the agents' step t+1 recomputed around the agents and patched into the result.
+    // Needs no per-step world reductions (the caller passed world_alive == NULL); the last step of the
+    // call stays an ordinary step, so the handle ends exactly as after K calls of dw_step.
+    const bool may_pair = h->allow_fuse && h->use_stream && bn && N <= kLookaheadMaxAgents && !world_alive &&
+                          policy_mode != kPolicySkipAgents && p.precision != DW_PRECISION_F64 &&
+                          !std::getenv("DW_NO_AGENT_FUSE");
     for (size_t t = 0; t < K; ++t) {
+        const bool pair = may_pair && h->cur_quantised && K - t >= 3;
         if (bn && policy_mode != kPolicySkipAgents) {
             const bool from_table = policy_mode == DW_POLICY_TABLE || (use_table && use_table[t]);
             if (from_table) {
                 hipLaunchKernelGGL(actions_from_table, dim3((unsigned)((bn + 255) / 256)), dim3(256), 0, h->stream,
                                    reinterpret_cast<const signed char*>(h->ep_buf + o_tab + t * bn), (int)bn, h->action);
+                hipLaunchKernelGGL(policy_greedy, dim3((unsigned)((bn + 255) / 256)), dim3(256), 0, h->stream,
+                                   h->L32[h->cur], h->D32[h->cur], h->idx, B, N, p.height, p.width, p.obs_mask, 0,
+                                   (const int*)nullptr, h->action, 1);      // codes -1 / -2: greedy / anti-greedy
             } else if (policy_mode == DW_POLICY_ZEROS) {
                 HIPCHK(hipMemsetAsync(h->action, 0, sizeof(int) * bn, h->stream));
             } else {
@@ -1382,6 +1394,39 @@ static int run_episode_stepwise(dw_handle* h, int32_t nsteps, const double* L_sc
             HIPCHK(hipGetLastError());
             int rc = launch_agents(h, h->action, B, N);
             if (rc) return rc;
+        }
+        if (pair) {
+            hipLaunchKernelGGL(agent_flags, dim3((unsigned)((bn + 255) / 256)), dim3(256), 0, h->stream, h->st, (int)bn,
+                               h->ep_buf + o_ok + t * bn);
+            const double L1 = L_schedule[t], L2 = L_schedule[t + 1];
+            int rc = launch_forward_fused2(h, L1, L2);
+            if (rc) return rc;
+            // codes of step t+1: the caller's table slice, or one byte value for the whole ensemble
+            const bool tab2 = policy_mode == DW_POLICY_TABLE || (use_table && use_table[t + 1]);
+            unsigned char* codes = h->ep_buf + o_code;
+            if (tab2) {
+                codes = h->ep_buf + o_tab + (t + 1) * bn;
+            } else {
+                const int v = policy_mode == DW_POLICY_ZEROS ? 0 : (policy_mode == DW_POLICY_ARGMIN ? 0xFE : 0xFF);
+                HIPCHK(hipMemsetAsync(codes, v, bn, h->stream));
+            }
+            LookaheadArgs A;
+            A.inL = h->L32[1 - h->cur]; A.inD = h->D32[1 - h->cur];
+            A.outL = h->L32[h->cur]; A.outD = h->D32[h->cur];
+            A.idx = h->idx; A.st = h->st;
+            A.code = reinterpret_cast<const signed char*>(codes);
+            A.agent_ok = h->ep_buf + o_ok + (t + 1) * bn;
+            A.B = B; A.N = N; A.H = p.height; A.W = p.width; A.mask = p.obs_mask;
+            A.agent_gamma = p.agent_gamma;
+            A.P1 = derive_f32(p, L1); A.P2 = derive_f32(p, L2);
+            A.P64 = make_f64(p, L1); A.La = L1; A.Lb = L2;
+            if (p.precision == DW_PRECISION_EXACT)
+                hipLaunchKernelGGL((agents_lookahead_patch<true>), dim3((unsigned)B), dim3(64), 0, h->stream, A);
+            else
+                hipLaunchKernelGGL((agents_lookahead_patch<false>), dim3((unsigned)B), dim3(64), 0, h->stream, A);
+            HIPCHK(hipGetLastError());
+            ++t;                                             // two steps done
+            continue;
         }
         int rc = launch_forward(h, L_schedule[t]);
         if (rc) return rc;

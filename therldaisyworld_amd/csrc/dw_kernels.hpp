@@ -9,6 +9,7 @@
 //   dw_episode.hpp        episode_small     K steps in one launch with the worlds in LDS (H*W <= 4096)
 //   dw_agents.hpp         agents_update (ref :181-244), observe (ref get_obs :246-263), policy_greedy
 //                         (agents/greedy.py:14-36), policy_mlp (agents/mlp.py:97-116), reward/done, lifespans
+//   dw_agents_fused.hpp   agents_lookahead_patch: the agents' step between the two steps of a fused launch
 //   dw_state_io.hpp       materialise (ref self.grid :445-459 / :304-323), init_random (Philox), conversions
 //
 // Wavefront = 64 lanes, 256-thread workgroups (4 waves), no MFMA: a single step is HBM-bound (16
@@ -23,3 +24,4 @@
 #include "dw_episode.hpp"
 #include "dw_agents.hpp"
 #include "dw_state_io.hpp"
+#include "dw_agents_fused.hpp"

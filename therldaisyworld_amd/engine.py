@@ -237,9 +237,12 @@ class Engine:
     def snapshot_restore(self):
         check(self._lib.dw_snapshot_restore(self._h))
 
-    def run_episode(self, L_schedule, policy_mode, use_table=None, table=None, threshold_k=5):
+    def run_episode(self, L_schedule, policy_mode, use_table=None, table=None, threshold_k=5, world_flags=True):
         """K device-resident steps (one launch for H*W <= 4096, back-to-back launches otherwise).
-        Returns (world_alive (K,B) bool, agent_ok (K,B,N) bool)."""
+        Returns (world_alive (K,B) bool, agent_ok (K,B,N) bool).  `table` entries: 0..8 an action, -1 / -2 the
+        greedy / anti-greedy choice of that agent at that step.  world_flags=False: the per-step world
+        reductions are not needed (world_alive is returned as None), which lets wide grids run step PAIRS in
+        one fused launch with the agents' in-between step patched in (dw_agents_fused.hpp)."""
         Ls = np.ascontiguousarray(L_schedule, dtype=np.float64)
         K = Ls.shape[0]
         ut = None if use_table is None else np.ascontiguousarray(use_table, dtype=np.uint8)
@@ -248,13 +251,13 @@ class Engine:
             raise ValueError("use_table must have shape (K,)")
         if tb is not None and tb.shape != (K, self.B, self.N):
             raise ValueError(f"table must have shape {(K, self.B, self.N)}")
-        alive = np.zeros((K, self.B), dtype=np.uint8)
+        alive = np.zeros((K, self.B), dtype=np.uint8) if world_flags else None
         ok = np.zeros((K, self.B, self.N), dtype=np.uint8)
         check(self._lib.dw_run_episode(
             self._h, K, _ffi.ptr_d(Ls), int(policy_mode), _ffi.ptr_u8(ut),
             None if tb is None else tb.ctypes.data_as(C.POINTER(C.c_int8)), int(threshold_k), _ffi.ptr_u8(alive),
             _ffi.ptr_u8(ok) if self.N else None))
-        return alive.astype(bool), ok.astype(bool)
+        return (None if alive is None else alive.astype(bool)), ok.astype(bool)
 
     def run_episode_mlp(self, L_schedule, params, member_a=None, member_b=None, split=None, L_init=0.75):
         """K device-resident steps with MLP policies: agents [0, split) of world b use parameter set
