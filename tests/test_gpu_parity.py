@@ -617,6 +617,46 @@ def test_lifespan_harness_on_large_worlds_uses_device_reductions(amd):
         assert np.array_equal(x, y)
 
 
+def test_episode_table_codes_for_greedy_choices(amd):
+    """Table entries -1 / -2 (greedy / anti-greedy choice of that agent at that step) in the LDS-resident
+    episode kernel and in the per-step launch path: both equal policy_per_agent + step."""
+    from therldaisyworld_amd import _ffi
+    B, G, N, K = 7, 16, 4, 9
+    rng = np.random.RandomState(3)
+    table = rng.randint(-2, 9, size=(K, B, N)).astype(np.int8)
+    outs = []
+    for mode in ("lds", "launches", "manual"):
+        eng = _engine(amd, B, G, G, N, "exact")
+        eng.init_random(8)
+        eng.step(0.9, np.zeros((B, N, 1), dtype=int))
+        Ls = [0.92 + 0.01 * i for i in range(K)]
+        if mode == "manual":
+            ok = np.zeros((K, B, N), bool)
+            for t in range(K):
+                for code, argmin in ((-1, False), (-2, True)):          # whole-ensemble greedy pass, then pick
+                    eng.policy_greedy(argmin=argmin)
+                    g = eng.download_actions()
+                    table_t = table[t].astype(np.int32)
+                    table[t] = np.where(table_t == code, g, table_t).astype(np.int8)
+                eng.upload_actions(table[t].astype(np.int32))
+                eng.step_device_actions(Ls[t])
+                ok[t] = ~eng.reward_done()[1][..., 0]
+        else:
+            if mode == "launches":
+                import os
+                os.environ["DW_NO_EPISODE_KERNEL"] = "1"
+            try:
+                _, ok = eng.run_episode(Ls, _ffi.POLICY_TABLE, None, table.copy())
+            finally:
+                import os
+                os.environ.pop("DW_NO_EPISODE_KERNEL", None)
+        outs.append((ok, *eng.download_planes(), *eng.download_agents()))
+        eng.close()
+    for other in outs[1:]:
+        for x, y in zip(outs[0], other):
+            assert np.array_equal(x, y)
+
+
 @pytest.mark.parametrize("B,H,W", [(9, 32, 32), (3, 72, 72), (2, 40, 256), (2, 66, 520)])
 def test_run_episode_matches_stepwise_engine(amd, B, H, W):
     """dw_run_episode == K x (policy + dw_step): planes, agents, flags, reductions, previous state —

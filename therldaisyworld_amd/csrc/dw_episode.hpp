@@ -82,9 +82,15 @@ __global__ __launch_bounds__(256) void episode_small(EpisodeIO io, int B, int N,
         if (valid && policy_mode != kPolicySkipAgents) {
             for (int n = lt; n < N; n += tpw) {
                 int a = 0;
+                bool greedy = false, argmin = policy_mode == kPolicyArgmin;
                 if (policy_mode == kPolicyTable || (policy_mode != kPolicyZeros && io.use_table[t])) {
-                    a = io.table[((size_t)t * B + b) * N + n];
+                    a = io.table[((size_t)t * B + b) * N + n];          // 0..8, or -1 / -2: (anti-)greedy choice
+                    greedy = a < 0;
+                    if (greedy) argmin = a == -2;
                 } else if (policy_mode != kPolicyZeros) {
+                    greedy = true;
+                }
+                if (greedy) {
                     const int ar = aidx[2 * n], ac = aidx[2 * n + 1];
                     const int cand[4] = {3, 1, 7, 5};             // (r,c-1) (r-1,c) (r+1,c) (r,c+1)
                     int best = 0;
@@ -97,7 +103,7 @@ __global__ __launch_bounds__(256) void episode_small(EpisodeIO io, int B, int N,
                             const int r = (ar + (k / 3 - 1) + H) % H, c = (ac + (k % 3 - 1) + W) % W;
                             v = (double)curL[r * W + c] / 1000.0 + (double)curD[r * W + c] / 1000.0;
                         }
-                        if (i == 0 || (policy_mode == kPolicyArgmin ? v < bestv : v > bestv)) { best = i; bestv = v; }
+                        if (i == 0 || (argmin ? v < bestv : v > bestv)) { best = i; bestv = v; }
                     }
                     a = 4 + best;
                 }
