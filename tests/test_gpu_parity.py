@@ -738,6 +738,35 @@ def test_agent_step_pairs_equal_single_steps(amd, monkeypatch, B, H, W, N, preci
         assert np.array_equal(x, y)
 
 
+@pytest.mark.parametrize("B,H,W,N", [(3, 40, 256, 3), (2, 70, 320, 2), (9, 16, 32, 4), (33, 8, 8, 5)])
+@pytest.mark.parametrize("precision", ["exact", "fast"])
+def test_agent_step_pairs_with_world_flags_through_the_death_of_the_worlds(amd, monkeypatch, B, H, W, N, precision):
+    """With per-step "biosphere alive" flags requested the step pairs use the STATS variants of the fused
+    kernels (exact step-1 maximum; count of certain step-2 values above the threshold, with a full scan of
+    the patched result for dying worlds): flags of every step, agent flags and final state equal the
+    one-launch-per-step path while the luminosity is driven up until every world is dead."""
+    from therldaisyworld_amd import _ffi
+    K = 45
+    outs = []
+    for pairs in (True, False):
+        if pairs:
+            monkeypatch.delenv("DW_NO_AGENT_FUSE", raising=False)
+        else:
+            monkeypatch.setenv("DW_NO_AGENT_FUSE", "1")
+        eng = _engine(amd, B, H, W, N, precision)
+        eng.init_random(17)
+        L = eng.step_n(60, 0.9, 0.004, 0.75, 1.5)           # grow a biosphere first (agents idle)
+        eng.step(L, np.zeros((B, N, 1), dtype=int))
+        Ls = [min(L + 0.03 * (i + 1), 2.4) for i in range(K)]   # then overheat it
+        alive, ok = eng.run_episode(Ls, _ffi.POLICY_ARGMAX, threshold_k=5)
+        outs.append((alive, ok, *eng.download_planes(), *eng.download_agents(), eng.reduce().tobytes()))
+        eng.close()
+    a, b = outs
+    assert a[0][0].all() and not a[0][-1].any()              # alive at first, dead at the end
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+
+
 @pytest.mark.parametrize("B,H,W,N", [(4, 16, 16, 3), (2, 64, 256, 2)])
 def test_snapshot_restore_replays_identically(amd, B, H, W, N):
     """dw_snapshot_save / dw_snapshot_restore: after a restore the same steps give the same state

@@ -63,6 +63,10 @@ struct LookaheadArgs {
     int* idx; double* st;                        // agents after step t, updated to step t+1
     const signed char* code;                     // [B][N] for step t+1: 0..8 action, -1 greedy argmax, -2 argmin
     unsigned char* agent_ok;                     // [B][N] reward >= 0.1 after step t+1, or null
+    // per-step "biosphere alive" flags (max cover > thr/1000) of the two steps, or null; pstats[2b], [2b+1]:
+    // the fused launch's exact step-1 maximum and its count of certain step-2 row groups above thr
+    unsigned char* alive_t; unsigned char* alive_t1;
+    const unsigned int* pstats; unsigned int thr;
     int B, N, H, W, mask;
     double agent_gamma;
     PhysF32 P1, P2;                              // float32 coefficient sets of steps t, t+1 (fast mode)
@@ -181,6 +185,24 @@ __global__ __launch_bounds__(64) void agents_lookahead_patch(LookaheadArgs A) {
         const size_t off = woff + (size_t)xr * W + xc;
         A.outL[off] = (float)(out & 0xffffu);
         A.outD[off] = (float)(out >> 16);
+    }
+
+    // ---- D: the two steps' "biosphere alive" flags ----
+    if (A.alive_t) {
+        if (lane == 0) A.alive_t[b] = A.pstats[2 * b] > A.thr ? 1 : 0;                       // max of S1
+        // step t+1: the fused launch counted row groups that certainly hold a value > thr; the patches
+        // above touched at most 9 * ng cells, i.e. at most 9 * ng groups.  More groups than that: alive,
+        // without looking.  Otherwise (a dying world) look at every cell of the patched result.
+        if (A.pstats[2 * b + 1] > 9u * (unsigned int)ng) {
+            if (lane == 0) A.alive_t1[b] = 1;
+        } else {
+            __threadfence_block();
+            __syncthreads();                                     // the patch stores of this block
+            float m = 0.f;
+            for (int i = lane; i < H * W; i += 64) m = fmaxf(m, fmaxf(A.outL[woff + i], A.outD[woff + i]));
+            m = wave_max(m);
+            if (lane == 0) A.alive_t1[b] = m > (float)A.thr ? 1 : 0;
+        }
     }
 }
 

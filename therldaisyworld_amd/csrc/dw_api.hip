@@ -458,7 +458,8 @@ static int launch_forward(dw_handle* h, double L) {
 // Two steps (luminosities L1 then L2) in one launch: float32-only mode, wide grids, no agent update in
 // between.  The buffer that held the input now holds the state TWO steps back, so the retained
 // "previous state" is not valid afterwards; dw_step_n always ends with an ordinary single step.
-static int launch_forward_fused2(dw_handle* h, double L1, double L2) {
+static int launch_forward_fused2(dw_handle* h, double L1, double L2, unsigned int* pstats = nullptr,
+                                 float thr_hi = 0.f) {
     const dw_params& p = h->prm;
     const int in = h->cur, out = 1 - h->cur;
     PhysF32 P1, P2;
@@ -471,20 +472,18 @@ static int launch_forward_fused2(dw_handle* h, double L1, double L2) {
     const bool rot = p.width == 256, pack = p.width < 256;
     if (p.precision == DW_PRECISION_EXACT) {
         const FusedExactArgs A{h->L32[in], h->D32[in], h->L32[out], h->D32[out], g, P1, lum_part(P2), zero_me, zero_n,
-                               make_f64(p, L1), L1, L2};
-        if (pack) hipLaunchKernelGGL((step_stream_fused2_exact<true, true>), grid, dim3(256), 0, h->stream, A);
-        else if (rot) hipLaunchKernelGGL((step_stream_fused2_exact<true>), grid, dim3(256), 0, h->stream, A);
-        else hipLaunchKernelGGL((step_stream_fused2_exact<false>), grid, dim3(256), 0, h->stream, A);
+                               pstats, thr_hi, make_f64(p, L1), L1, L2};
+#define DW_FX(R, P, S) hipLaunchKernelGGL((step_stream_fused2_exact<R, P, S>), grid, dim3(256), 0, h->stream, A)
+        if (pstats) { if (pack) DW_FX(true, true, true); else if (rot) DW_FX(true, false, true); else DW_FX(false, false, true); }
+        else { if (pack) DW_FX(true, true, false); else if (rot) DW_FX(true, false, false); else DW_FX(false, false, false); }
+#undef DW_FX
     } else {
-        if (pack)
-            hipLaunchKernelGGL((step_stream_fused2<true, true>), grid, dim3(256), 0, h->stream, h->L32[in], h->D32[in],
-                               h->L32[out], h->D32[out], g, P1, P2, zero_me, zero_n);
-        else if (rot)
-            hipLaunchKernelGGL((step_stream_fused2<true>), grid, dim3(256), 0, h->stream, h->L32[in], h->D32[in],
-                               h->L32[out], h->D32[out], g, P1, P2, zero_me, zero_n);
-        else
-            hipLaunchKernelGGL((step_stream_fused2<false>), grid, dim3(256), 0, h->stream, h->L32[in], h->D32[in],
-                               h->L32[out], h->D32[out], g, P1, P2, zero_me, zero_n);
+#define DW_FF(R, P, S)                                                                                             \
+    hipLaunchKernelGGL((step_stream_fused2<R, P, S>), grid, dim3(256), 0, h->stream, h->L32[in], h->D32[in], h->L32[out], \
+                       h->D32[out], g, P1, P2, zero_me, zero_n, pstats, thr_hi)
+        if (pstats) { if (pack) DW_FF(true, true, true); else if (rot) DW_FF(true, false, true); else DW_FF(false, false, true); }
+        else { if (pack) DW_FF(true, true, false); else if (rot) DW_FF(true, false, false); else DW_FF(false, false, false); }
+#undef DW_FF
     }
     HIPCHK(hipGetLastError());
     h->cur = out;
@@ -1358,7 +1357,7 @@ static int run_episode_stepwise(dw_handle* h, int32_t nsteps, const double* L_sc
     const size_t K = (size_t)nsteps, bn = (size_t)B * N;
     auto up = [](size_t v) { return (v + 255) / 256 * 256; };
     const size_t o_tab = 0, o_wa = up(o_tab + K * bn), o_ok = up(o_wa + K * B), o_code = up(o_ok + K * bn);
-    const size_t total = up(o_code + bn) + 256;
+    const size_t o_ps = up(o_code + bn), total = up(o_ps + sizeof(unsigned int) * 2 * B) + 256;
     if (h->ep_bytes < total) {
         if (h->ep_buf) HIPCHK(hipFree(h->ep_buf));
         h->ep_buf = nullptr; h->ep_bytes = 0;
@@ -1371,9 +1370,12 @@ static int run_episode_stepwise(dw_handle* h, int32_t nsteps, const double* L_sc
     // forward_{t+1}, then the agents' step t+1 recomputed around the agents and patched into the result.
     // Needs no per-step world reductions (the caller passed world_alive == NULL); the last step of the
     // call stays an ordinary step, so the handle ends exactly as after K calls of dw_step.
-    const bool may_pair = h->allow_fuse && h->use_stream && bn && N <= kLookaheadMaxAgents && !world_alive &&
+    const bool may_pair = h->allow_fuse && h->use_stream && bn && N <= kLookaheadMaxAgents &&
                           policy_mode != kPolicySkipAgents && p.precision != DW_PRECISION_F64 &&
                           !std::getenv("DW_NO_AGENT_FUSE");
+    // With per-step world flags the fused launch also reduces what the flags of both steps need (STATS
+    // variants: exact step-1 maximum, count of certain step-2 values above the threshold).
+    unsigned int* pstats = world_alive ? reinterpret_cast<unsigned int*>(h->ep_buf + o_ps) : nullptr;
     for (size_t t = 0; t < K; ++t) {
         const bool pair = may_pair && h->cur_quantised && K - t >= 3;
         if (bn && policy_mode != kPolicySkipAgents) {
@@ -1399,7 +1401,8 @@ static int run_episode_stepwise(dw_handle* h, int32_t nsteps, const double* L_sc
             hipLaunchKernelGGL(agent_flags, dim3((unsigned)((bn + 255) / 256)), dim3(256), 0, h->stream, h->st, (int)bn,
                                h->ep_buf + o_ok + t * bn);
             const double L1 = L_schedule[t], L2 = L_schedule[t + 1];
-            int rc = launch_forward_fused2(h, L1, L2);
+            if (pstats) HIPCHK(hipMemsetAsync(pstats, 0, sizeof(unsigned int) * 2 * B, h->stream));
+            int rc = launch_forward_fused2(h, L1, L2, pstats, (float)threshold_k);
             if (rc) return rc;
             // codes of step t+1: the caller's table slice, or one byte value for the whole ensemble
             const bool tab2 = policy_mode == DW_POLICY_TABLE || (use_table && use_table[t + 1]);
@@ -1416,6 +1419,9 @@ static int run_episode_stepwise(dw_handle* h, int32_t nsteps, const double* L_sc
             A.idx = h->idx; A.st = h->st;
             A.code = reinterpret_cast<const signed char*>(codes);
             A.agent_ok = h->ep_buf + o_ok + (t + 1) * bn;
+            A.alive_t = pstats ? h->ep_buf + o_wa + t * B : nullptr;
+            A.alive_t1 = pstats ? h->ep_buf + o_wa + (t + 1) * B : nullptr;
+            A.pstats = pstats; A.thr = threshold_k;
             A.B = B; A.N = N; A.H = p.height; A.W = p.width; A.mask = p.obs_mask;
             A.agent_gamma = p.agent_gamma;
             A.P1 = derive_f32(p, L1); A.P2 = derive_f32(p, L2);

@@ -98,12 +98,18 @@ constexpr int kMismatchCap = 64;            // float32 step-1 mismatches per wav
 // PACK (with ROT): narrow worlds (W | 256) side by side in the wave row, as in step_stream<halo=packed>:
 // every lane has its own world, the horizontal wrap is a rotation inside the world's lane group, and a
 // local column lc of the wave row decodes to (world, column) = (lc / W, lc % W).
-template <bool ROT, bool EXACT, bool PACK = false>
+// STATS: what an episode harness needs from a step pair with agents in between (dw_agents_fused.hpp):
+//   pstats[2*world]     max over the world's exact step-1 values (the "biosphere alive" flag of step t)
+//   pstats[2*world + 1] number of this world's output row groups (4 cells of a lane) holding a step-2
+//                       value above `thr_hi` that cannot be an artefact of float32 or be undone by the few
+//                       cells patched afterwards - a sound lower bound, see agents_lookahead_patch.
+template <bool ROT, bool EXACT, bool PACK = false, bool STATS = false>
 __device__ __forceinline__ void fused2_body(const float* __restrict__ inL, const float* __restrict__ inD,
                                             float* __restrict__ outL, float* __restrict__ outD, const FusedGeom& G,
                                             const PhysF32& P1, const PhysF32& P2, const PhysF64& P64,
                                             const double& La, const double& Lb,
-                                            unsigned long long* __restrict__ zero_me, int zero_n) {
+                                            unsigned long long* __restrict__ zero_me, int zero_n,
+                                            unsigned int* __restrict__ pstats = nullptr, float thr_hi = 0.f) {
     __shared__ uint4 s_queue[EXACT ? 4 * kWaveQueueCap * 3 : 1];
     __shared__ unsigned int s_mm[EXACT ? 4 * kMismatchCap : 1];
     const int bid = blockIdx.x;
@@ -173,16 +179,25 @@ __device__ __forceinline__ void fused2_body(const float* __restrict__ inL, const
         D = make_row(d, a, c);
     };
     unsigned int nq = 0;                                        // queued entries of this wave (uniform)
+    float st_m1 = 0.f;                                          // STATS accumulators of this lane
+    unsigned int st_c2 = 0, st_nmm = 0;
     // one row of the map with coefficient set P: (up, mid, down) -> new values; exact mode also queues
     // the near-tie cells (kind 1 = step 1, 2 = step 2; lrow = row index relative to grid row r0-2)
     auto row_map = [&](const PhysF32& P, const Row4& upL, const Row4& miL, const Row4& dnL, const Row4& upD,
-                       const Row4& miD, const Row4& dnD, float4& nl, float4& nd, int kind, int lrow, const bool* use) {
+                       const Row4& miD, const Row4& dnD, float4& nl, float4& nd, int kind, int lrow, const bool* use,
+                       float* sure_max = nullptr) {
         float ol[4], od[4];
         bool tie[4];
         cells4<EXACT>(P, upL, miL, dnL, upD, miD, dnD, ol, od, tie);
         if (EXACT) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) tie[i] = tie[i] && use[i];
+        }
+        if (STATS && sure_max) {                                 // max over the cells whose float32 value is certain
+            float m = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) m = fmaxf(m, (EXACT && tie[i]) ? 0.f : fmaxf(ol[i], od[i]));
+            *sure_max = m;
         }
         nl = make_float4(ol[0], ol[1], ol[2], ol[3]);
         nd = make_float4(od[0], od[1], od[2], od[3]);
@@ -210,12 +225,16 @@ __device__ __forceinline__ void fused2_body(const float* __restrict__ inL, const
         const Raw nx = load_raw(r0 + j);                       // input row j+2, needed by the NEXT iteration
         __builtin_amdgcn_sched_barrier(0);
         float4 l1, d1;
-        row_map(P1, IL[(u + 2) % 3], IL[u], IL[(u + 1) % 3], ID[(u + 2) % 3], ID[u], ID[(u + 1) % 3], l1, d1, 1, j, need1);
+        float sm = 0.f;
+        row_map(P1, IL[(u + 2) % 3], IL[u], IL[(u + 1) % 3], ID[(u + 2) % 3], ID[u], ID[(u + 1) % 3], l1, d1, 1, j, need1,
+                STATS ? &sm : nullptr);
+        if (STATS && writes && j >= 2 && j <= nr + 1) st_m1 = fmaxf(st_m1, sm);   // step-1 rows of MY output cells
         to_rows4(l1, d1, SL[u], SD[u]);                        // step-1 row j replaces step-1 row j-3
         if (j >= 3) {
             float4 l2, d2;
             row_map(P2, SL[(u + 1) % 3], SL[(u + 2) % 3], SL[u], SD[(u + 1) % 3], SD[(u + 2) % 3], SD[u], l2, d2, 2, j - 1,
-                    use2);
+                    use2, STATS ? &sm : nullptr);
+            if (STATS && writes && sm > thr_hi) st_c2 += 1u;
             if (writes) {
                 const size_t off = woff + (size_t)(r0 + j - 3) * G.W + col;
                 stream_store4(outL + off, l2);
@@ -249,6 +268,7 @@ __device__ __forceinline__ void fused2_body(const float* __restrict__ inL, const
             gc = c00 + lc;
             gc = gc < 0 ? gc + G.W : (gc >= G.W ? gc - G.W : gc);
         };
+        auto world_of = [&](int lc) -> int { return PACK ? min(b * G.wpr + (lc >> 2) / G.lpw, G.B - 1) : b; };
         // world base and grid coordinates of a local (row, column); false if the column's world is missing
         auto locate = [&](int lrow, int lc, size_t& wo, int& gr, int& gc) -> bool {
             grid_rc(lrow, lc, gr, gc);
@@ -289,6 +309,11 @@ __device__ __forceinline__ void fused2_body(const float* __restrict__ inL, const
                     where = e0.y;
                     if (e0.x == 1u) {
                         mism = (kl | (kd << 16)) != unpack_ld(e2.w);
+                        if (STATS && is_output((int)(where >> 16), (int)(where & 0xffffu))) {   // exact value of a tie cell
+                            const unsigned int mx = kl > kd ? kl : kd;
+                            if (PACK) atomicMax(&pstats[2 * world_of((int)(where & 0xffffu))], mx);   // any world of the row
+                            else st_m1 = fmaxf(st_m1, (float)mx);              // my wave's world: reduced below
+                        }
                     } else {
                         int gr, gc;
                         size_t wo;
@@ -379,19 +404,56 @@ __device__ __forceinline__ void fused2_body(const float* __restrict__ inL, const
                 const size_t off = wo + (size_t)gr * G.W + gc;
                 outL[off] = kl;
                 outD[off] = kd;
+                if (STATS) {                                     // step-1 maximum from scratch; no step-2 count
+                    const unsigned int w1 = exact1_word(inL + wo, inD + wo, G.H, G.W, gr, gc, Pa);
+                    atomicMax(&pstats[2 * world_of(lc)], (w1 & 0xffffu) > (w1 >> 16) ? (w1 & 0xffffu) : (w1 >> 16));
+                }
+            }
+            st_m1 = 0.f;
+            st_c2 = 0;
+        }
+        st_nmm = nmm;
+    }
+    if (STATS) {
+        // This wave's contribution.  The counted row groups hold a non-tie step-2 value > thr_hi, i.e. a
+        // value whose float32 rounding is the exact one - unless a step-1 input was a mismatch: those cells
+        // are the <= 9 per mismatch that F3 rewrote, so 9 * nmm groups are deducted (a sound lower bound).
+        if (PACK) {
+            float m = st_m1;
+            unsigned int c = st_c2;
+            for (int o = G.lpw >> 1; o > 0; o >>= 1) {
+                m = fmaxf(m, __shfl_xor(m, o, 64));
+                c += (unsigned int)__shfl_xor((int)c, o, 64);
+            }
+            c = c > 9u * st_nmm ? c - 9u * st_nmm : 0u;
+            if (pj == 0 && writes) {
+                atomicMax(&pstats[2 * (b * G.wpr + pw)], (unsigned int)m);
+                if (c) atomicAdd(&pstats[2 * (b * G.wpr + pw) + 1], c);
+            }
+        } else {
+            const float m = wave_max(st_m1);
+            unsigned int c = st_c2;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) c += (unsigned int)__shfl_xor((int)c, o, 64);
+            c = c > 9u * st_nmm ? c - 9u * st_nmm : 0u;
+            if (lane == 0) {
+                atomicMax(&pstats[2 * b], (unsigned int)m);
+                if (c) atomicAdd(&pstats[2 * b + 1], c);
             }
         }
     }
 }
 
-template <bool ROT, bool PACK = false>
+template <bool ROT, bool PACK = false, bool STATS = false>
 __global__ __launch_bounds__(256) void step_stream_fused2(const float* __restrict__ inL, const float* __restrict__ inD,
                                                           float* __restrict__ outL, float* __restrict__ outD,
                                                           FusedGeom G, PhysF32 P1, PhysF32 P2,
-                                                          unsigned long long* __restrict__ zero_me, int zero_n) {
+                                                          unsigned long long* __restrict__ zero_me, int zero_n,
+                                                          unsigned int* __restrict__ pstats, float thr_hi) {
     const PhysF64 dummy{};
     const double zero = 0.0;
-    fused2_body<ROT, false, PACK>(inL, inD, outL, outD, G, P1, P2, dummy, zero, zero, zero_me, zero_n);
+    fused2_body<ROT, false, PACK, STATS>(inL, inD, outL, outD, G, P1, P2, dummy, zero, zero, zero_me, zero_n, pstats,
+                                         thr_hi);
 }
 
 #ifndef DW_FUSED_EXACT_WAVES
@@ -404,16 +466,17 @@ struct FusedExactArgs {
                                                                   // 15 shared constants instead of 2 x 23 (each
                                                                   // one occupies an SGPR PAIR as a packed operand)
     unsigned long long* zero_me; int zero_n;
+    unsigned int* pstats; float thr_hi;                           // STATS variants only
     PhysF64 P64; double La; double Lb;                            // cold (see kernarg_struct)
 };
 
-template <bool ROT, bool PACK = false>
+template <bool ROT, bool PACK = false, bool STATS = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DW_FUSED_EXACT_WAVES, DW_FUSED_EXACT_WAVES)))
 void step_stream_fused2_exact(FusedExactArgs A) {
     const FusedExactArgs& cold = kernarg_struct<FusedExactArgs>();
     const PhysF32 P2 = with_lum(A.P1, A.lum2);
-    fused2_body<ROT, true, PACK>(A.inL, A.inD, A.outL, A.outD, A.G, A.P1, P2, cold.P64, cold.La, cold.Lb, A.zero_me,
-                           A.zero_n);
+    fused2_body<ROT, true, PACK, STATS>(A.inL, A.inD, A.outL, A.outD, A.G, A.P1, P2, cold.P64, cold.La, cold.Lb,
+                                        A.zero_me, A.zero_n, A.pstats, A.thr_hi);
 }
 
 }  // namespace dw
