@@ -123,6 +123,20 @@ static int ensure_scratch(dw_handle* h, size_t bytes) {
     return DW_OK;
 }
 
+// episode staging buffer (schedules, tables, per-step flags): grown geometrically from 4 MiB so that a
+// longer chunk after a short one does not pay a synchronous hipFree + hipMalloc inside a timed run
+static int ensure_ep_buf(dw_handle* h, size_t bytes) {
+    if (h->ep_bytes >= bytes) return DW_OK;
+    size_t want = h->ep_bytes ? h->ep_bytes * 2 : ((size_t)4 << 20);
+    if (want < bytes) want = bytes;
+    if (h->ep_buf) HIPCHK(hipFree(h->ep_buf));
+    h->ep_buf = nullptr;
+    h->ep_bytes = 0;
+    HIPCHK(hipMalloc(&h->ep_buf, want));
+    h->ep_bytes = want;
+    return DW_OK;
+}
+
 // near-tie queues of the exact mode: room for 1/64 of all cells (the bound flags ~0.3-0.5 %), at
 // least 2048 entries per queue; 48 bytes per entry, i.e. 0.75 B per cell on top of the 16 B of state
 static int ensure_fixq(dw_handle* h) {
@@ -1258,12 +1272,7 @@ int dw_run_episode_mlp(dw_handle* h, int32_t nsteps, const double* L_schedule, c
     const size_t wbytes = sizeof(double) * 1808 * (size_t)n_members;
     const size_t o_w = 0, o_ma = up(o_w + wbytes), o_mb = up(o_ma + sizeof(int) * B), o_r = up(o_mb + sizeof(int) * B);
     const size_t o_d = up(o_r + sizeof(double) * K * bn), total = up(o_d + K * bn);
-    if (h->ep_bytes < total) {
-        if (h->ep_buf) HIPCHK(hipFree(h->ep_buf));
-        h->ep_buf = nullptr; h->ep_bytes = 0;
-        HIPCHK(hipMalloc(&h->ep_buf, total));
-        h->ep_bytes = total;
-    }
+    if (int erc = ensure_ep_buf(h, total)) return erc;
     const double* d_w = reinterpret_cast<const double*>(h->ep_buf + o_w);
     const int* d_ma = member_a ? reinterpret_cast<const int*>(h->ep_buf + o_ma) : nullptr;
     const int* d_mb = member_b ? reinterpret_cast<const int*>(h->ep_buf + o_mb) : nullptr;
@@ -1358,12 +1367,7 @@ static int run_episode_stepwise(dw_handle* h, int32_t nsteps, const double* L_sc
     auto up = [](size_t v) { return (v + 255) / 256 * 256; };
     const size_t o_tab = 0, o_wa = up(o_tab + K * bn), o_ok = up(o_wa + K * B), o_code = up(o_ok + K * bn);
     const size_t o_ps = up(o_code + bn), total = up(o_ps + sizeof(unsigned int) * 2 * B) + 256;
-    if (h->ep_bytes < total) {
-        if (h->ep_buf) HIPCHK(hipFree(h->ep_buf));
-        h->ep_buf = nullptr; h->ep_bytes = 0;
-        HIPCHK(hipMalloc(&h->ep_buf, total));
-        h->ep_bytes = total;
-    }
+    if (int erc = ensure_ep_buf(h, total)) return erc;
     if (table && bn) HIPCHK(hipMemcpyAsync(h->ep_buf + o_tab, table, K * bn, hipMemcpyHostToDevice, h->stream));
     const int nflag = B > (int)bn ? B : (int)bn;
     // Step pairs on wide grids (dw_agents_fused.hpp): policy_t, graze_t, ONE fused launch for forward_t and
@@ -1466,7 +1470,7 @@ static int run_episode_impl(dw_handle* h, int32_t nsteps, const double* L_schedu
         return run_episode_stepwise(h, nsteps, L_schedule, policy_mode, use_table, table, threshold_k, world_alive,
                                     agent_ok);
     const int wpb = C <= 256 ? 4 : (C <= 1024 ? 2 : 1);
-    const size_t world_bytes = ((size_t)16 * C + (size_t)N * 8 + (size_t)N * 12 + 16 + 15) / 16 * 16;
+    const size_t world_bytes = episode_world_bytes(C, N);
     const size_t lds = world_bytes * wpb;
     NEED(lds <= 160 * 1024, DW_EINVAL, "too many agents for the LDS-resident episode kernel");
     // device staging: [P32 K][Ls K][use_table K][table K*B*N][world_alive K*B][agent_ok K*B*N]
@@ -1474,12 +1478,7 @@ static int run_episode_impl(dw_handle* h, int32_t nsteps, const double* L_schedu
     auto up = [](size_t v) { return (v + 255) / 256 * 256; };
     const size_t o_p32 = 0, o_ls = up(o_p32 + sizeof(PhysF32) * K), o_ut = up(o_ls + sizeof(double) * K);
     const size_t o_tab = up(o_ut + K), o_wa = up(o_tab + K * bn), o_ok = up(o_wa + K * B), total = up(o_ok + K * bn);
-    if (h->ep_bytes < total) {
-        if (h->ep_buf) HIPCHK(hipFree(h->ep_buf));
-        h->ep_buf = nullptr; h->ep_bytes = 0;
-        HIPCHK(hipMalloc(&h->ep_buf, total));
-        h->ep_bytes = total;
-    }
+    if (int erc = ensure_ep_buf(h, total)) return erc;
     std::vector<PhysF32> p32(K);
     for (size_t t = 0; t < K; ++t) p32[t] = derive_f32(p, L_schedule[t]);
     std::vector<unsigned char> ut(K, 0);

@@ -40,6 +40,31 @@ struct EpisodeIO {
     unsigned long long* fixups;     // out: float64 re-evaluations of the last step (summed)
 };
 
+// float64 value of cell c of an LDS-resident world (exact mode's re-evaluation of a near-tie cell)
+__device__ inline float ep_cell_f64(const PhysF64& Q, const float* curL, const float* curD, int H, int W, int c,
+                                    float& kd) {
+    const int r = c / W, cc = c - r * W;
+    const int ru = (r == 0 ? H - 1 : r - 1) * W, rm = r * W, rd = (r == H - 1 ? 0 : r + 1) * W;
+    const int cl = cc == 0 ? W - 1 : cc - 1, cr = cc == W - 1 ? 0 : cc + 1;
+    const int rows[3] = {ru, rm, rd}, cols[3] = {cl, cc, cr};
+    unsigned int wv[9];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int e = 0; e < 3; ++e)
+            wv[a * 3 + e] = (unsigned)curL[rows[a] + cols[e]] | ((unsigned)curD[rows[a] + cols[e]] << 16);
+    const NewCoverF64 o = cell_f64_lean(Q, wv);
+    kd = (float)dw_round3_k(o.nd);
+    return (float)dw_round3_k(o.nl);
+}
+
+// LDS bytes of one world: planes [2 buffers][2 species][C] floats | agent states | idx, act | 8 reduction
+// words | the step's near-tie cell list (exact mode)
+constexpr int kEpFixCap = 240;
+__host__ __device__ constexpr size_t episode_world_bytes(int C, int N) {
+    return ((size_t)16 * C + (size_t)N * 8 + (size_t)N * 12 + 32 + 2 * kEpFixCap + 15) / 16 * 16;
+}
+
 template <bool EXACT>
 __global__ __launch_bounds__(256) void episode_small(EpisodeIO io, int B, int N, int H, int W, int wpb, int K,
                                                      int policy_mode, int obs_mask, double agent_gamma,
@@ -50,14 +75,15 @@ __global__ __launch_bounds__(256) void episode_small(EpisodeIO io, int B, int N,
     const int tid = threadIdx.x, w = tid / tpw, lt = tid - w * tpw;
     const int b = blockIdx.x * wpb + w;
     const bool valid = b < B;
-    // LDS carve-up per world: planes [2 buffers][2 species][C] floats | agent state doubles | idx | act | red
-    const size_t world_bytes = ((size_t)16 * C + (size_t)N * 8 + (size_t)N * 12 + 16 + 15) / 16 * 16;
+    // LDS carve-up per world: planes [2 buffers][2 species][C] floats | agent state doubles | idx | act | red | list
+    const size_t world_bytes = episode_world_bytes(C, N);
     unsigned char* base = smem + (size_t)w * world_bytes;
     float* planes = reinterpret_cast<float*>(base);
     double* ast = reinterpret_cast<double*>(base + (size_t)16 * C);
     int* aidx = reinterpret_cast<int*>(base + (size_t)16 * C + (size_t)N * 8);
     int* act = aidx + 2 * N;
-    unsigned int* red = reinterpret_cast<unsigned int*>(act + N);   // max, sum_l, sum_d, fixups
+    unsigned int* red = reinterpret_cast<unsigned int*>(act + N);   // max, sum_l, sum_d, fixups, [4] = list length
+    unsigned short* fixlist = reinterpret_cast<unsigned short*>(red + 8);   // cells to re-evaluate in float64
     float* curL = planes;
     float* curD = planes + C;
     float* nxtL = planes + 2 * C;
@@ -73,7 +99,7 @@ __global__ __launch_bounds__(256) void episode_small(EpisodeIO io, int B, int N,
             aidx[2 * n] = io.idx[((size_t)b * N + n) * 2];
             aidx[2 * n + 1] = io.idx[((size_t)b * N + n) * 2 + 1];
         }
-        if (lt < 4) red[lt] = 0;
+        if (lt < 8) red[lt] = 0;
     }
     __syncthreads();
 
@@ -165,16 +191,16 @@ __global__ __launch_bounds__(256) void episode_small(EpisodeIO io, int B, int N,
                     kl = finish_exact(P, li, g.gql, g.dKl, g.oml, tl);
                     kd = finish_exact(P, di, g.gqd, g.dKd, g.omd, td);
                     if (tl || td) {
-                        const int rows[3] = {ru, rm, rd}, cols[3] = {cl, cc, cr};
-                        unsigned int wv[9];
-#pragma unroll
-                        for (int a = 0; a < 3; ++a)
-#pragma unroll
-                            for (int e = 0; e < 3; ++e)
-                                wv[a * 3 + e] = (unsigned)curL[rows[a] + cols[e]] | ((unsigned)curD[rows[a] + cols[e]] << 16);
-                        const NewCoverF64 o = cell_f64_lean(Q, wv);
-                        kl = (float)dw_round3_k(o.nl);
-                        kd = (float)dw_round3_k(o.nd);
+                        // near a tie: re-evaluated in float64 AFTER the loop, by all threads of the world at
+                        // once (inline, every such cell would cost its whole wave a float64 evaluation)
+                        const unsigned int slot = atomicAdd(&red[4], 1u);
+                        if (slot < (unsigned)kEpFixCap) {
+                            fixlist[slot] = (unsigned short)c;
+                            nxtL[c] = kl;                       // provisional; kept out of the reductions
+                            nxtD[c] = kd;
+                            continue;
+                        }
+                        kl = ep_cell_f64(Q, curL, curD, H, W, c, kd);      // list full: on the spot
                         ++nfix;
                     }
                 } else {
@@ -187,6 +213,25 @@ __global__ __launch_bounds__(256) void episode_small(EpisodeIO io, int B, int N,
                 tsl += kl;
                 tsd += kd;
             }
+        }
+        if (EXACT) {
+            __syncthreads();                                     // the list is complete
+            if (valid) {
+                const unsigned int n = min(red[4], (unsigned)kEpFixCap);
+                for (unsigned int e = lt; e < n; e += tpw) {
+                    const int c = fixlist[e];
+                    float kd;
+                    const float kl = ep_cell_f64(Q, curL, curD, H, W, c, kd);
+                    nxtL[c] = kl;
+                    nxtD[c] = kd;
+                    tmax = fmaxf(tmax, fmaxf(kl, kd));
+                    tsl += kl;
+                    tsd += kd;
+                    ++nfix;
+                }
+            }
+            __syncthreads();
+            if (valid && lt == 0) red[4] = 0;
         }
         // per-world reductions: wavefront shuffles when a wave belongs to one world, LDS atomics across waves
         {
