@@ -1183,6 +1183,34 @@ def test_policy_per_agent_modes(amd):
     env.close()
 
 
+@pytest.mark.parametrize("B,H,W", [(1024, 256, 256), (2, 4096, 4096), (3000, 64, 64)])
+@pytest.mark.parametrize("precision", ["exact", "fast"])
+def test_full_size_translation_invariance_and_checksums(amd, B, H, W, precision):
+    """Size-independent properties at BASELINE's full sizes (C2; 4096-wide worlds; a packed ensemble), where
+    the CPU oracle is too slow: the map commutes with translations of the torus (every strip, halo and
+    world-group boundary is exercised, in both modes bit for bit), fused step pairs included, and the
+    per-world reductions equal the checksums of the downloaded planes."""
+    eng = _engine(amd, B, H, W, 0, precision)
+    eng.init_random(123)
+    eng.step(0.9)                                            # quantised start
+    l0, d0 = eng.download_planes()
+    L = eng.step_n(7, 0.91, 0.01, 0.75, 1.5)
+    l1, d1 = eng.download_planes()
+    s = eng.reduce()
+    assert np.array_equal(s["sum_light_k"], np.rint(l1 * 1000).sum(axis=(1, 2)).astype(np.uint64))
+    assert np.array_equal(s["sum_dark_k"], np.rint(d1 * 1000).sum(axis=(1, 2)).astype(np.uint64))
+    assert np.array_equal(s["max_k"], np.rint(np.maximum(l1.max(axis=(1, 2)), d1.max(axis=(1, 2))) * 1000))
+    dr, dc = 37 % H, 101 % W
+    eng.upload_state_f32(np.roll(l0, (dr, dc), axis=(1, 2)).astype(np.float32),
+                         np.roll(d0, (dr, dc), axis=(1, 2)).astype(np.float32), quantised=True)
+    L2 = eng.step_n(7, 0.91, 0.01, 0.75, 1.5)
+    l2, d2 = eng.download_planes()
+    assert L2 == L
+    assert np.array_equal(l2, np.roll(l1, (dr, dc), axis=(1, 2)))
+    assert np.array_equal(d2, np.roll(d1, (dr, dc), axis=(1, 2)))
+    eng.close()
+
+
 def test_exact_mode_full_ramp_soak_vs_oracle(amd):
     """The whole luminosity ramp (512 steps: growth, pattern formation, die-off) of 8 worlds of 256x256
     in exact mode with fused step pairs against the float64 C oracle: 2.7e8 cell-updates, bit-identical
