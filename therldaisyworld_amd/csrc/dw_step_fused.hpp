@@ -168,8 +168,8 @@ __device__ __forceinline__ void fused2_body(const float* __restrict__ inL, const
     };
     auto nbrs = [&](const float4& v, float& a, float& c) {
         if (PACK) { a = __shfl(v.w, lsrc, 64); c = __shfl(v.x, rsrc, 64); }
-        else if (ROT) { a = dpp_mov<kDppWaveRor1>(0.f, v.w); c = dpp_mov<kDppWaveRol1>(0.f, v.x); }
-        else { a = dpp_mov<kDppWaveShr1>(0.f, v.w); c = dpp_mov<kDppWaveShl1>(0.f, v.x); }   // lanes 0/63: unused
+        else if (ROT) { a = dpp_mov_nb<kDppWaveRor1>(v.w); c = dpp_mov_nb<kDppWaveRol1>(v.x); }
+        else { a = dpp_mov_nb<kDppWaveShr1>(v.w); c = dpp_mov_nb<kDppWaveShl1>(v.x); }   // lanes 0/63: unused
     };
     auto to_rows4 = [&](const float4& l, const float4& d, Row4& L, Row4& D) {
         float a, c;

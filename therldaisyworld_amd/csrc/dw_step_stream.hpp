@@ -91,6 +91,17 @@ __device__ __forceinline__ float dpp_mov(float old, float src) {
 #endif
 }
 
+// the same move when no lane needs an `old` value (rotations; shifts whose edge lane is unused): bound_ctrl
+// lets the hardware supply 0 there, so no register has to be zeroed for the tied destination
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov_nb(float src) {
+#ifdef DW_NO_DPP
+    return dpp_mov<CTRL>(0.f, src);
+#else
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(src), CTRL, 0xf, 0xf, true));
+#endif
+}
+
 // left / right neighbour values of the lane's 4-column group for one plane
 // HALO: 0 = W == 256 (wrap inside the wave), 1 = W % 256 == 0, 2 = any other W >= 256,
 //       3 = packed: W in {8,...,128} divides 256, a wave row holds 256/W worlds side by side and the
@@ -102,8 +113,8 @@ __device__ __forceinline__ void lr_neighbours(const float4& v, float halo, int l
         lnb = __shfl(v.w, lsrc, 64);
         rnb = __shfl(v.x, rsrc, 64);
     } else if (HALO == 0) {              // toroidal wrap inside the wave
-        lnb = dpp_mov<kDppWaveRor1>(0.f, v.w);
-        rnb = dpp_mov<kDppWaveRol1>(0.f, v.x);
+        lnb = dpp_mov_nb<kDppWaveRor1>(v.w);
+        rnb = dpp_mov_nb<kDppWaveRol1>(v.x);
     } else if (HALO == 1) {              // lane 0 / lane 63 keep `old` = their halo value
         lnb = dpp_mov<kDppWaveShr1>(halo, v.w);
         rnb = dpp_mov<kDppWaveShl1>(halo, v.x);
