@@ -172,6 +172,12 @@ int dw_download_caches(dw_handle* h, double L, double* temps, double* betas, dou
  * Asynchronous. */
 int dw_step(dw_handle* h, const int32_t* action, int32_t action_b, int32_t action_n, double L);
 
+/* dw_step followed by dw_get_obs and dw_get_reward_done with a single synchronisation: what one call of the
+ * reference's step() returns (ref :475-497: obs, reward, done), for latency-bound small batches.  obs /
+ * reward / done may be NULL. */
+int dw_env_step(dw_handle* h, const int32_t* action, int32_t action_b, int32_t action_n, double L,
+                double* obs /* [B][N][7][3][3] */, double* reward /* [B][N] */, uint8_t* done /* [B][N] */);
+
 /* Same, taking the actions from the handle's device action buffer (filled by dw_policy_greedy or
  * dw_upload_actions) — keeps an episode loop free of host round trips. */
 int dw_step_device_actions(dw_handle* h, double L);

@@ -80,6 +80,7 @@ SIGNATURES = {
     "dw_policy_per_agent": (C.c_int, [_vp, _pi]),
     "dw_policy_mlp": (C.c_int, [_vp, _pd, _i32, _i32, _i32, _dbl]),
     "dw_policy_mlp_population": (C.c_int, [_vp, _pd, _i32, _pi, _i32, _i32, _dbl]),
+    "dw_env_step": (C.c_int, [_vp, _pi, _i32, _i32, _dbl, _pd, _pd, _pu8]),
     "dw_snapshot_save": (C.c_int, [_vp]),
     "dw_snapshot_restore": (C.c_int, [_vp]),
     "dw_lifespan_reset": (C.c_int, [_vp]),

@@ -95,6 +95,8 @@ struct dw_handle {
     double* reward_d = nullptr;       // [B][N]
     unsigned char* done_d = nullptr;  // [B][N]
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    unsigned char* pinned = nullptr;  // page-locked host staging of dw_env_step (actions in, obs/reward/done out)
+    size_t pinned_bytes = 0;
     // dw_snapshot_save / dw_snapshot_restore: device copy of the current state
     float* snapL = nullptr;
     float* snapD = nullptr;
@@ -112,6 +114,7 @@ static int run_episode_impl(dw_handle* h, int32_t nsteps, const double* L_schedu
                             const uint8_t* use_table, const int8_t* table, uint32_t threshold_k,
                             uint8_t* world_alive, uint8_t* agent_ok);
 static bool episode_kernel_applies(const dw_handle* h);
+static int observe_into_scratch(dw_handle* h, double L_init, size_t extra_bytes);
 
 static int ensure_scratch(dw_handle* h, size_t bytes) {
     if (h->scratch_bytes >= bytes) return DW_OK;
@@ -642,6 +645,7 @@ int dw_destroy(dw_handle* h) {
     (void)hipFree(h->L64); (void)hipFree(h->D64);
     (void)hipFree(h->idx); (void)hipFree(h->st); (void)hipFree(h->action); (void)hipFree(h->action_tmp);
     (void)hipFree(h->reward_d); (void)hipFree(h->done_d);
+    if (h->pinned) (void)hipHostFree(h->pinned);
     (void)hipFree(h->snapL); (void)hipFree(h->snapD); (void)hipFree(h->snap_idx); (void)hipFree(h->snap_st);
     (void)hipFree(h->snap_stats);
     (void)hipFree(h->agents_done_at); (void)hipFree(h->done_at); (void)hipFree(h->n_alive);
@@ -1100,6 +1104,63 @@ int dw_get_obs(dw_handle* h, double L_init, double* obs) {
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(obs, h->scratch, sizeof(double) * bn * 63, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    return DW_OK;
+}
+
+// step + get_obs + reward/done as one call.  Everything crosses PCIe through one page-locked staging
+// buffer (pageable copies are staged and serialised by the runtime, ~20 us each): actions in, the three
+// results out, all asynchronous on the handle's stream with ONE synchronisation.
+int dw_env_step(dw_handle* h, const int32_t* action, int32_t action_b, int32_t action_n, double L, double* obs,
+                double* reward, uint8_t* done) {
+    NEED(h, DW_EINVAL, "null handle");
+    const dw_params& p = h->prm;
+    HIPCHK(hipSetDevice(p.device));
+    const size_t bn = (size_t)p.batch * p.n_agents;
+    auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+    const size_t o_act = 0, o_obs = up(sizeof(int) * bn), o_rew = up(o_obs + sizeof(double) * bn * 63);
+    const bool big_obs = sizeof(double) * bn * 63 > ((size_t)512 << 10);
+    const size_t o_done = up(o_rew + sizeof(double) * bn), total = up(o_done + bn) + 256;
+    if (h->pinned_bytes < total) {
+        if (h->pinned) HIPCHK(hipHostFree(h->pinned));
+        h->pinned = nullptr; h->pinned_bytes = 0;
+        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h->pinned), total, hipHostMallocDefault));
+        h->pinned_bytes = total;
+    }
+    if (action) {
+        NEED(action_b >= 0 && action_n >= 0 && action_b <= p.batch && action_n <= p.n_agents, DW_EINVAL,
+             "action block %dx%d exceeds (B,N)=(%d,%d)", action_b, action_n, p.batch, p.n_agents);
+        const size_t na = (size_t)action_b * action_n;
+        if (na) {
+            std::memcpy(h->pinned + o_act, action, sizeof(int) * na);
+            HIPCHK(hipMemcpyAsync(h->action_tmp, h->pinned + o_act, sizeof(int) * na, hipMemcpyHostToDevice, h->stream));
+        }
+        int rc = launch_agents(h, h->action_tmp, action_b, action_n);
+        if (rc) return rc;
+    }
+    int rc = launch_forward(h, L);
+    if (rc) return rc;
+    if (bn) {
+        NEED(h->have_agents, DW_ESTATE, "no agents");
+        if (obs) {
+            rc = observe_into_scratch(h, L, 0);
+            if (rc) return rc;
+            // big observation blocks go straight to the caller's array (the extra host copy would cost more
+            // than the staged pageable transfer)
+            HIPCHK(hipMemcpyAsync(big_obs ? static_cast<void*>(obs) : static_cast<void*>(h->pinned + o_obs), h->scratch,
+                                  sizeof(double) * bn * 63, hipMemcpyDeviceToHost, h->stream));
+        }
+        if (reward || done) {
+            hipLaunchKernelGGL(reward_done, dim3((unsigned)((bn + 255) / 256)), dim3(256), 0, h->stream, h->st, h->reward_d,
+                               h->done_d, (int)bn);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(h->pinned + o_rew, h->reward_d, sizeof(double) * bn, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipMemcpyAsync(h->pinned + o_done, h->done_d, bn, hipMemcpyDeviceToHost, h->stream));
+        }
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (obs && !big_obs) std::memcpy(obs, h->pinned + o_obs, sizeof(double) * bn * 63);
+        if (reward) std::memcpy(reward, h->pinned + o_rew, sizeof(double) * bn);
+        if (done) std::memcpy(done, h->pinned + o_done, bn);
+    }
     return DW_OK;
 }
 

@@ -413,13 +413,15 @@ class RLDaisyWorld:
         if self.collision_mode == 1 and action is not None:
             self._update_agents_on_device(action)             # device move/graze + host collision pass
             action = None
-        eng.step(self.L, action)
-        self._L_pass = self.L
-        self._invalidate()
-        obs = eng.get_obs(self._L_pass)
         if self.n_agents:
-            reward, _ = eng.reward_done()
+            obs, reward, _ = eng.env_step(self.L, action)        # one call, one synchronisation
+            self._L_pass = self.L
+            self._invalidate()
         else:
+            eng.step(self.L, action)
+            self._L_pass = self.L
+            self._invalidate()
+            obs = eng.get_obs(self._L_pass)
             s = eng.reduce()
             reward = np.stack([s["sum_light_k"] > 0, s["sum_dark_k"] > 0], axis=-1)
         reward = reward * (reward > 0)

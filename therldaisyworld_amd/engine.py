@@ -135,6 +135,21 @@ class Engine:
             a = self._actions(action)
             check(self._lib.dw_step(self._h, _ffi.ptr_i(a), a.shape[0], a.shape[1], float(L)))
 
+    def env_step(self, L, action=None):
+        """step + get_obs + reward/done in one call with one synchronisation.  Returns
+        (obs (B,N,7,3,3), reward (B,N,1), done (B,N,1) bool)."""
+        obs = np.zeros((self.B, self.N, 7, 3, 3))
+        reward = np.zeros((self.B, self.N, 1))
+        done = np.zeros((self.B, self.N, 1), dtype=np.uint8)
+        if action is None:
+            a, ab, an = None, 0, 0
+        else:
+            a = self._actions(action)
+            ab, an = a.shape
+        check(self._lib.dw_env_step(self._h, _ffi.ptr_i(a), ab, an, float(L), _ffi.ptr_d(obs), _ffi.ptr_d(reward),
+                                    _ffi.ptr_u8(done)))
+        return obs, reward, done.astype(bool)
+
     def step_device_actions(self, L):
         check(self._lib.dw_step_device_actions(self._h, float(L)))
 
