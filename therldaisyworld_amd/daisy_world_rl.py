@@ -178,8 +178,8 @@ class RLDaisyWorld:
         if self._grid_m is not None and self._grid_m.dirty():
             g = self._grid_m.array
             eng.upload_state(g[:, 1], g[:, 2])
-            self._grid_m = None
-            self._caches = {}
+            self._grid_m.snapshot = g.copy()          # the edited array stays the environment's grid (as in the
+            self._caches = {}                         # reference, where it IS the state) until the next step
         if self._idx_m is not None and (not self._agents_on_device or self._idx_m.dirty() or self._st_m.dirty()):
             eng.upload_agents(self._idx_m.array, self._st_m.array[..., 0])
             self._idx_m.snapshot = self._idx_m.array.copy()
@@ -324,21 +324,26 @@ class RLDaisyWorld:
     # the path
     # ------------------------------------------------------------------------------------------
     def get_obs(self, agent_indices=None):
-        """ref :246-263."""
+        """ref :246-263: the 3x3 wrap-around patches of ALL channels of self.grid around the given positions,
+        times the neighbourhood mask.  While the device state is the only copy (no grid handed out since the
+        last step / reset) and the positions are the environment's own, the observe kernel builds them
+        directly; otherwise they are what the reference computes: slices of the host grid, whose channels
+        may be stale or edited by the caller."""
         eng = self._ensure_engine()
-        if agent_indices is not None and self._idx_m is not None and agent_indices is not self._idx_m.array:
-            if not np.array_equal(agent_indices, self._idx_m.array):
-                # observations around caller-supplied positions: temporary upload
-                saved = self._idx_m.array
-                self._idx_m.array = np.array(agent_indices, dtype=np.int64)
-                self._agents_on_device = False
-                self._sync_to_device()
-                obs = eng.get_obs(self._L_pass)
-                self._idx_m.array = saved
-                self._agents_on_device = False
-                return obs
-        self._sync_to_device()
-        return eng.get_obs(self._L_pass)
+        own = agent_indices is None or (self._idx_m is not None and (
+            agent_indices is self._idx_m.array or np.array_equal(agent_indices, self._idx_m.array)))
+        if own and self._grid_m is None:
+            self._sync_to_device()
+            return eng.get_obs(self._L_pass)
+        grid = self.grid
+        idx = np.asarray(self.agent_indices if agent_indices is None else agent_indices).astype(np.int64)
+        B, N = idx.shape[:2]
+        off = np.arange(-1, 2)
+        rows = (idx[..., 0, None] + off) % self.dim                       # (B,N,3)
+        cols = (idx[..., 1, None] + off) % self.dim
+        obs = grid[np.arange(B)[:, None, None, None, None], np.arange(self.ch)[None, None, :, None, None],
+                   rows[:, :, None, :, None], cols[:, :, None, None, :]]
+        return obs * self.neighborhood
 
     def update_agents(self, action):
         """ref :181-244.  Movement and grazing run on the device; with collision_mode == 1 the
