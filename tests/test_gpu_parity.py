@@ -397,6 +397,24 @@ def test_dropin_direct_method_calls_g15(amd, golden):
     env.close()
 
 
+@pytest.mark.default_pack_threshold
+@pytest.mark.parametrize("seed", list(range(60000, 60016)))
+def test_dropin_random_operation_sequences_vs_oracle_environment(amd, seed):
+    """A slice of tools/fuzz_dropin.py in the suite: random sequences of steps (full / partial / None /
+    float actions), in-place edits and assignments of grid and agent arrays, get_obs elsewhere,
+    update_agents / forward as plain methods, live constant changes, resets, collision and neighbourhood
+    modes, cache reads - the drop-in against the NumPy oracle environment after every operation, RNG
+    stream in lock step."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_dropin.py")
+    spec = importlib.util.spec_from_file_location("fuzz_dropin", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    log = []
+    assert mod.run_case(seed, log), log
+
+
 def test_dropin_no_agents_g7(amd, golden):
     g = golden("G7_no_agents")
     np.random.seed(21)

@@ -45,9 +45,13 @@ def same(a, b, exact=True, rtol=1e-12):
 
 def run_case(seed, log):
     rng = np.random.RandomState(seed)
-    dim = int(rng.choice([5, 8, 12, 16, 20]))
+    dim = int(rng.choice([5, 8, 12, 16, 20, 64, 256]))
     N = int(rng.randint(0, 5))
     kw = dict(grid_dimension=dim, n_agents=N)
+    if rng.rand() < 0.25:
+        kw["collision_mode"] = 1                               # RNG-coupled collision pass (ref :220-242)
+    if rng.rand() < 0.3:
+        kw["neighborhood_mode"] = str(rng.choice(["moore", "circular", "von_neumann"]))
     envs = []
     for make in (lambda: Oracle(**kw), lambda: amd.RLDaisyWorld(**kw)):
         np.random.seed(seed)
@@ -86,7 +90,7 @@ def run_case(seed, log):
         return (e.grid.copy(), np.asarray(e.agent_indices).copy(), np.asarray(e.agent_states).copy(),
                 np.float64(e.L), np.float64(e.dL), np.int64(e.step_count))
 
-    B = int(rng.choice([1, 3, 6]))
+    B = int(rng.choice([1, 3, 6])) if dim <= 64 else int(rng.choice([1, 2]))
 
     def do_reset(e):
         e.batch_size = B
@@ -97,7 +101,8 @@ def run_case(seed, log):
         return False
     for step in range(int(rng.randint(6, 16))):
         op = rng.choice(["step", "step", "step", "step_none", "step_sub", "edit_grid", "assign_grid", "edit_agents",
-                         "get_obs", "update_agents", "forward", "mutate_reset", "read_caches", "read_caches"])
+                         "get_obs", "update_agents", "forward", "mutate_reset", "read_caches", "read_caches",
+                         "mutate_live", "reset_plain"])
         n_now = int(dev.n_agents)
         if op == "step" or (op in ("step_sub", "edit_agents", "get_obs", "update_agents") and n_now == 0):
             a = rng.randint(9, size=(B, n_now, 1)).astype(float if rng.rand() < 0.3 else int) if n_now else None
@@ -138,6 +143,18 @@ def run_case(seed, log):
             def fn(e):
                 new = e.forward(e.grid)
                 return (new, *snapshot(e))
+        elif op == "mutate_live":                           # constants the next physics pass must already see
+            dt, ag = float(rng.choice([0.5, 1.0, 2.0])), float(rng.choice([0.02, 0.05, 0.1]))
+            micro, newL = bool(rng.randint(2)), float(rng.uniform(0.8, 1.4))
+            def fn(e, dt=dt, ag=ag, micro=micro, newL=newL):
+                e.dt, e.agent_gamma = dt, ag
+                e.q2 = e.q / 8.0 if micro else 0.0          # ref set_use_microclimate :85-92
+                e.L = newL
+                return snapshot(e)
+        elif op == "reset_plain":
+            def fn(e):
+                obs = e.reset()
+                return (obs, *snapshot(e))
         elif op == "read_caches":                           # what notebook_helpers.py:45-55 reads after a step
             if not stepped:
                 continue
@@ -154,7 +171,7 @@ def run_case(seed, log):
                 e.batch_size = B
                 obs = e.reset()
                 return (obs, *snapshot(e))
-        exact = quantised and op not in ("mutate_reset",)
+        exact = quantised and op not in ("mutate_reset", "reset_plain")
         if op in ("step", "step_none", "step_sub"):
             exact = True                                   # a step rounds every channel it returns
         if op == "read_caches":
@@ -166,7 +183,7 @@ def run_case(seed, log):
         stepped = op in ("step", "step_none", "step_sub", "forward")
         if op in ("step", "step_none", "step_sub", "assign_grid"):
             quantised = op != "assign_grid" or quantised
-        if op == "mutate_reset":
+        if op in ("mutate_reset", "reset_plain"):
             quantised = False
     dev.close()
     return True
