@@ -415,6 +415,23 @@ def test_dropin_random_operation_sequences_vs_oracle_environment(amd, seed):
     assert mod.run_case(seed, log), log
 
 
+@pytest.mark.parametrize("seed", [10005, 10010, 10012, 10033, 10040, 10041, 10042, 10043])
+def test_lifespan_harness_random_configurations_vs_notebook_loop_on_oracle(amd, seed):
+    """A slice of tools/fuzz_harness.py: the chunked, device-resident lifespan harness against the
+    notebook's loop on the NumPy oracle environment (lifespans, final state, RNG stream).  The first four
+    seeds are episodes whose last world dies exactly on the last step of a chunk (a case the harness once
+    ran past)."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_harness.py")
+    spec = importlib.util.spec_from_file_location("fuzz_harness", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    log = []
+    ok, info = mod.run_case(seed, log)
+    assert ok, log
+
+
 def test_dropin_no_agents_g7(amd, golden):
     g = golden("G7_no_agents")
     np.random.seed(21)

@@ -122,7 +122,7 @@ def simulate_lifespan(env, agent, chunk=32, use_device_loop=True, obs=None):
             env._L_pass = env.L
             env.L = env.update_L(env.L)
         env._invalidate()
-        if executed < K:
+        if all_dead.any():                                 # also when the last world died on the chunk's last step
             return done_at, agents_done_at
 
 
