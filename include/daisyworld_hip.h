@@ -254,13 +254,12 @@ int dw_run_episode_mlp(dw_handle* h, int32_t nsteps, const double* L_schedule, c
                        int32_t n_members, const int32_t* member_a /* [B] */, const int32_t* member_b /* [B] */,
                        int32_t split, double L_init, double* reward /* [K][B][N] */, uint8_t* done /* [K][B][N] */);
 
-/* Device-side snapshot of the current state (both planes, agents, per-world reductions) and its
- * restoration: lets an episode harness run chunks of steps ahead (dw_run_episode) and, when the episode
+/* Device-side snapshot of the handle's state (current planes, the retained previous state that
+ * observations and caches are derived from, agents, per-world reductions) and its restoration: lets an episode harness run chunks of steps ahead (dw_run_episode) and, when the episode
  * turns out to have ended inside a chunk, replay exactly the steps the reference's loop
  * (notebooks/greedy_longevity_abatement.ipynb cell 2:28-57: stop as soon as every world is dead) would
- * have executed — without moving the state over PCIe.  Costs one extra copy of the two planes in HBM,
- * allocated at the first save.  After a restore the retained "previous state" is not the predecessor of
- * the current one until the next step. */
+ * have executed — without moving the state over PCIe.  Costs up to two extra copies of the two planes
+ * in HBM, allocated at the first save. */
 int dw_snapshot_save(dw_handle* h);
 int dw_snapshot_restore(dw_handle* h);
 

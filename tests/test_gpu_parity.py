@@ -1048,6 +1048,23 @@ def test_get_fitness_early_stop_inside_a_chunk(amd, chunk):
         assert np.array_equal(x, y)
 
 
+@pytest.mark.parametrize("seed", [10005, 10023, 10025, 10031, 10048, 10050, 10051, 10052])
+def test_get_fitness_random_configurations_vs_reference_arithmetic_on_oracle(amd, seed):
+    """A slice of tools/fuzz_fitness.py: the chunked ES fitness harness against sges.get_fitness's loop on the
+    oracle environment with OracleMLP policies (fitness, counters, final state).  The first five seeds stop
+    early inside a chunk with observation-dependent policies: the replay from the snapshot must see the same
+    retained previous state (temperature channels of the observations) as the original run."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_fitness.py")
+    spec = importlib.util.spec_from_file_location("fuzz_fitness", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    log = []
+    ok, info = mod.run_case(seed, log)
+    assert ok, log
+
+
 def test_trained_mlp_rollout_on_device_matches_reference_fixture_g11(amd, golden):
     """The trained policy the reference ships (results/cmaes_exp_002, generation 127) on the default
     16x16 world: policy_mlp on the device + step_device_actions for 160 steps reproduce the reference's

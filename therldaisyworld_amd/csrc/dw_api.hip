@@ -100,6 +100,11 @@ struct dw_handle {
     // dw_snapshot_save / dw_snapshot_restore: device copy of the current state
     float* snapL = nullptr;
     float* snapD = nullptr;
+    float* snapPL = nullptr;          // the retained previous state (observations, caches) when there is one
+    float* snapPD = nullptr;
+    bool snap_stepped = false;
+    double snap_L_last = 0.0;
+    F64Owner snap_f64 = F64_NONE;
     int* snap_idx = nullptr;
     double* snap_st = nullptr;
     unsigned char* snap_stats = nullptr;
@@ -647,6 +652,7 @@ int dw_destroy(dw_handle* h) {
     (void)hipFree(h->reward_d); (void)hipFree(h->done_d);
     if (h->pinned) (void)hipHostFree(h->pinned);
     (void)hipFree(h->snapL); (void)hipFree(h->snapD); (void)hipFree(h->snap_idx); (void)hipFree(h->snap_st);
+    (void)hipFree(h->snapPL); (void)hipFree(h->snapPD);
     (void)hipFree(h->snap_stats);
     (void)hipFree(h->agents_done_at); (void)hipFree(h->done_at); (void)hipFree(h->n_alive);
     (void)hipFree(h->stats2[0]); (void)hipFree(h->stats2[1]); (void)hipFree(h->scratch); (void)hipFree(h->ep_buf); (void)hipFree(h->fixq); (void)hipFree(h->redo_tiles);
@@ -1600,6 +1606,19 @@ int dw_snapshot_save(dw_handle* h) {
     HIPCHK(hipMemcpyAsync(h->snapL, h->L32[h->cur], sizeof(float) * h->cells, hipMemcpyDeviceToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->snapD, h->D32[h->cur], sizeof(float) * h->cells, hipMemcpyDeviceToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->snap_stats, h->stats2[h->sp], h->stats_bytes, hipMemcpyDeviceToDevice, h->stream));
+    // the previous state too: observations (temperature channels) and the temp / beta / growth caches are
+    // derived from it, so a replay from the snapshot must see the same one
+    h->snap_stepped = h->stepped;
+    h->snap_L_last = h->L_last;
+    h->snap_f64 = h->f64;
+    if (h->stepped && h->f64 != F64_PREV) {
+        if (!h->snapPL) {
+            HIPCHK(hipMalloc(&h->snapPL, sizeof(float) * h->cells));
+            HIPCHK(hipMalloc(&h->snapPD, sizeof(float) * h->cells));
+        }
+        HIPCHK(hipMemcpyAsync(h->snapPL, h->L32[1 - h->cur], sizeof(float) * h->cells, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->snapPD, h->D32[1 - h->cur], sizeof(float) * h->cells, hipMemcpyDeviceToDevice, h->stream));
+    }
     h->snap_agents = bn && h->have_agents;
     if (h->snap_agents) {
         HIPCHK(hipMemcpyAsync(h->snap_idx, h->idx, sizeof(int) * 2 * bn, hipMemcpyDeviceToDevice, h->stream));
@@ -1624,9 +1643,14 @@ int dw_snapshot_restore(dw_handle* h) {
         HIPCHK(hipMemcpyAsync(h->idx, h->snap_idx, sizeof(int) * 2 * bn, hipMemcpyDeviceToDevice, h->stream));
         HIPCHK(hipMemcpyAsync(h->st, h->snap_st, sizeof(double) * bn, hipMemcpyDeviceToDevice, h->stream));
     }
-    h->f64 = F64_NONE;
+    if (h->snap_stepped && h->snap_f64 != F64_PREV) {
+        HIPCHK(hipMemcpyAsync(h->L32[1 - h->cur], h->snapPL, sizeof(float) * h->cells, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->D32[1 - h->cur], h->snapPD, sizeof(float) * h->cells, hipMemcpyDeviceToDevice, h->stream));
+    }
+    h->f64 = h->snap_f64;                       // F64_PREV: the float64 copy of the initial state is still there
     h->cur_quantised = h->snap_quantised;
-    h->stepped = false;                         // the other buffer is no longer this state's predecessor
+    h->stepped = h->snap_stepped;
+    h->L_last = h->snap_L_last;
     return DW_OK;
 }
 
