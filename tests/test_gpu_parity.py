@@ -432,6 +432,29 @@ def test_lifespan_harness_random_configurations_vs_notebook_loop_on_oracle(amd, 
     assert ok, log
 
 
+@pytest.mark.default_pack_threshold
+@pytest.mark.parametrize("seed", list(range(70000, 70012)))
+def test_engine_random_call_sequences_vs_oracle_model(amd, seed):
+    """A slice of tools/fuzz_engine.py: random interleavings of the C ABI's state-changing calls against
+    the oracle model, everything compared after every operation."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_engine.py")
+    spec = importlib.util.spec_from_file_location("fuzz_engine", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    log = []
+    saved = os.environ.get("DW_PACK_MIN_STRIPS")
+    try:
+        ok, info = mod.run_case(seed, log)
+    finally:
+        if saved is None:
+            os.environ.pop("DW_PACK_MIN_STRIPS", None)
+        else:
+            os.environ["DW_PACK_MIN_STRIPS"] = saved
+    assert ok, log
+
+
 def test_dropin_no_agents_g7(amd, golden):
     g = golden("G7_no_agents")
     np.random.seed(21)
