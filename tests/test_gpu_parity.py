@@ -93,8 +93,10 @@ SHAPES = [
     (2, 50, 64),      # packed, H < one strip
     (2, 96, 128),     # packed: 2 worlds per wave row, two row strips
     (5, 130, 128),    # packed, three row strips, ragged group
-    (2, 40, 96),      # tiled TCQ=16 (W does not divide 256)
-    (2, 50, 192),     # tiled TCQ=32
+    (2, 40, 96),      # packed, W does not divide 256: 2 worlds on 48 lanes, 16 lanes idle
+    (2, 50, 192),     # packed: one world on 48 lanes
+    (5, 33, 100),     # packed: 2 worlds of 25 lanes, ragged group, odd group size (gathered reductions)
+    (2, 40, 132),     # 33 lanes of 64 would be used: left to the tiled kernel
     (2, 256, 256),    # wave-strip, wrap inside the wave (C2's shape)
     (1, 70, 320),     # wave-strip, general halo
     (1, 33, 516),     # wave-strip, general halo, W % 256 = 4
@@ -880,7 +882,8 @@ def test_c1_trajectory_via_episode_kernel_g2(amd, golden):
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("B,H,W", [(3, 256, 256), (2, 100, 256), (1, 70, 320), (1, 130, 516), (2, 64, 1024),
                                    (2, 3, 256), (1, 5, 500), (1, 65, 260),
-                                   (5, 64, 64), (3, 40, 128), (33, 8, 8), (2, 130, 32), (17, 16, 16)])   # packed
+                                   (5, 64, 64), (3, 40, 128), (33, 8, 8), (2, 130, 32), (17, 16, 16),   # packed
+                                   (3, 70, 96), (5, 20, 100), (2, 66, 192)])          # packed, W does not divide 256
 @pytest.mark.parametrize("nsteps", [3, 8, 13])
 @pytest.mark.parametrize("precision", ["fast", "exact"])
 def test_fused_step_pairs_equal_single_steps(amd, monkeypatch, B, H, W, nsteps, precision):
@@ -930,7 +933,8 @@ def test_fused_fast_trajectory_vs_oracle_tolerance(amd):
 
 
 @pytest.mark.parametrize("B,H,W", [(3, 256, 256), (1, 70, 320), (2, 64, 1024),
-                                   (5, 64, 64), (33, 8, 8), (3, 130, 128), (9, 20, 16)])               # packed
+                                   (5, 64, 64), (33, 8, 8), (3, 130, 128), (9, 20, 16),                # packed
+                                   (3, 70, 96), (5, 20, 100), (2, 66, 192)])
 def test_fused_exact_trajectory_bit_exact_vs_oracle(amd, monkeypatch, B, H, W):
     """Exact mode with fused step pairs against the float64 C oracle over 41 steps (20 fused launches +
     the float64 first step from the un-quantised device state): bit-identical planes."""
@@ -967,14 +971,18 @@ def test_fused_exact_other_constants_vs_oracle(amd, over, B, H, W):
     eng.close()
 
 
-@pytest.mark.parametrize("B,H,W,nsteps", [(2, 256, 256, 7), (1, 70, 320, 6), (2, 64, 128, 3), (2, 64, 192, 3),
-                                          (5, 64, 64, 6), (9, 16, 32, 5)])
+@pytest.mark.parametrize("B,H,W,nsteps,kernel", [(2, 256, 256, 7, None), (1, 70, 320, 6, None), (2, 64, 128, 3, None),
+                                                 (2, 64, 192, 3, None), (5, 64, 64, 6, None), (9, 16, 32, 5, None),
+                                                 (3, 50, 100, 5, None), (2, 64, 128, 3, "tiled"),
+                                                 (2, 64, 192, 3, "tiled"), (1, 70, 320, 4, "tiled")])
 @pytest.mark.parametrize("qcap,mcap", [(2, 64), (256, 0), (0, 0)])
-def test_exact_mode_overflow_fallbacks_are_exact(amd, monkeypatch, B, H, W, nsteps, qcap, mcap):
+def test_exact_mode_overflow_fallbacks_are_exact(amd, monkeypatch, B, H, W, nsteps, kernel, qcap, mcap):
     """Shrink the near-tie queues so that they overflow everywhere: the fallbacks (whole strip / tile
     recomputed in float64, single-step and fused kernels, packed and tiled shapes) must still give the
     oracle's result."""
     monkeypatch.setenv("DW_NO_EPISODE_KERNEL", "1")
+    if kernel:
+        monkeypatch.setenv("DW_KERNEL", kernel)
     monkeypatch.setenv("DW_TEST_QUEUE_CAP", str(qcap))
     monkeypatch.setenv("DW_TEST_MISMATCH_CAP", str(mcap))
     eng = _engine(amd, B, H, W, 0, "exact")

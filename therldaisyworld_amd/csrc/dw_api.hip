@@ -273,8 +273,12 @@ static void select_kernel(dw_handle* h) {
     // 64 rows, ~50 us, where the tiled kernel answers in ~9 us; DW_PACK_MIN_STRIPS overrides for tests)
     int pack_min_strips = 512;
     if (const char* e = std::getenv("DW_PACK_MIN_STRIPS")) pack_min_strips = std::atoi(e);
-    const bool pack_shape = p.width >= 8 && p.width <= 128 && 256 % p.width == 0 && !std::getenv("DW_NO_PACK");
-    const long pack_strips = pack_shape ? (long)((p.batch + 256 / p.width - 1) / (256 / p.width)) * ((p.height + 63) / 64) : 0;
+    // any width below 256 that is a multiple of 4, provided at least 70 % of the 64 lanes get columns
+    // (W = 96: 2 worlds on 48 lanes; W = 132: one world on 33 lanes - left to the tiled kernel)
+    const int pk_lpw = p.width / 4, pk_wpr = pk_lpw ? 64 / pk_lpw : 0;
+    const bool pack_shape = p.width >= 8 && p.width < 256 && pk_wpr >= 1 && pk_wpr * pk_lpw * 10 >= 64 * 7 &&
+                            !std::getenv("DW_NO_PACK");
+    const long pack_strips = pack_shape ? (long)((p.batch + pk_wpr - 1) / pk_wpr) * ((p.height + 63) / 64) : 0;
     const bool packable = pack_shape && pack_strips >= pack_min_strips;
     if ((p.width >= 256 || packable) && !(force && std::strcmp(force, "tiled") == 0)) {
         h->use_stream = true;
@@ -282,7 +286,7 @@ static void select_kernel(dw_handle* h) {
         g.B = p.batch; g.H = p.height; g.W = p.width;
         g.ncs = (p.width + 255) / 256;
         g.lpw = packable ? p.width / 4 : 64;
-        g.wpr = packable ? 256 / p.width : 1;
+        g.wpr = packable ? pk_wpr : 1;
         // Strip height: 64 rows (3 % halo re-reads) when that already gives every SIMD two strips; shorter
         // strips for smaller jobs - a strip is a serial march of ~0.8 us per row, so with few strips the
         // launch takes as long as ONE strip and most SIMDs idle.  DW_STRIP_ROWS overrides (experiments).

@@ -26,7 +26,7 @@ struct FusedGeom {
     int nstrips, nwg, chunk;
     int cols_per_strip;       // 256 (ROT) or 248 (OVL)
     int qcap, mcap;           // queue / mismatch-list capacities in use (tests shrink them)
-    int lpw, wpr;             // packed mode (W < 256, W | 256): lanes per world row, worlds per wave row
+    int lpw, wpr;             // packed mode (W < 256): lanes per world row (W/4), worlds per wave row (64 / lpw)
 };
 
 // float64 step-1 value of grid cell (r, c) (any integers: wrapped onto the torus) from the input planes,
@@ -133,14 +133,14 @@ __device__ __forceinline__ void fused2_body(const float* __restrict__ inL, const
     const int rsrc = PACK ? (pj == G.lpw - 1 ? lane - (G.lpw - 1) : lane + 1) : 0;
     // world base of a local column (PACK: the column's own world; lanes of missing worlds shadow the last)
     auto world_off = [&](int lc) -> size_t {
-        return (size_t)(PACK ? min(b * G.wpr + (lc >> 2) / G.lpw, G.B - 1) : b) * G.H * G.W;
+        return (size_t)(PACK ? min(b * G.wpr + min((lc >> 2) / G.lpw, G.wpr - 1), G.B - 1) : b) * G.H * G.W;
     };
     const size_t woff = world_off(4 * lane);
     const int c00 = ROT ? 0 : cs * 248 - 4;                     // grid column of local column 0 (may be -4)
     int col = PACK ? 4 * pj : c00 + 4 * lane;
     col = col < 0 ? col + G.W : col;
     col = col >= G.W ? col - G.W : col;                         // W >= 256 > 252: one wrap suffices
-    const bool writes = PACK ? (b * G.wpr + pw < G.B)
+    const bool writes = PACK ? (pw < G.wpr && b * G.wpr + pw < G.B)
                              : (ROT ? true : (lane >= 1 && lane <= 62 && cs * 248 + 4 * (lane - 1) < G.W));
     // which of my four step-1 cells feed an output cell of this wave (exact mode: only their ties matter)
     bool need1[4] = {true, true, true, true};
@@ -268,7 +268,9 @@ __device__ __forceinline__ void fused2_body(const float* __restrict__ inL, const
             gc = c00 + lc;
             gc = gc < 0 ? gc + G.W : (gc >= G.W ? gc - G.W : gc);
         };
-        auto world_of = [&](int lc) -> int { return PACK ? min(b * G.wpr + (lc >> 2) / G.lpw, G.B - 1) : b; };
+        auto world_of = [&](int lc) -> int {
+            return PACK ? min(b * G.wpr + min((lc >> 2) / G.lpw, G.wpr - 1), G.B - 1) : b;
+        };
         // world base and grid coordinates of a local (row, column); false if the column's world is missing
         auto locate = [&](int lrow, int lc, size_t& wo, int& gr, int& gc) -> bool {
             grid_rc(lrow, lc, gr, gc);
@@ -276,12 +278,12 @@ __device__ __forceinline__ void fused2_body(const float* __restrict__ inL, const
             if (!PACK) return true;
             const int pwc = (lc >> 2) / G.lpw;
             gc = lc - pwc * G.W;
-            return b * G.wpr + pwc < G.B;
+            return pwc < G.wpr && b * G.wpr + pwc < G.B;
         };
         // is local (row, column) an output cell of this wave?
         auto is_output = [&](int lrow, int lc) -> bool {
             if (lrow < 2 || lrow > nr + 1) return false;
-            if (PACK) return b * G.wpr + (lc >> 2) / G.lpw < G.B;
+            if (PACK) return (lc >> 2) / G.lpw < G.wpr && b * G.wpr + (lc >> 2) / G.lpw < G.B;
             if (ROT) return true;
             const int ln = lc >> 2;
             return lc >= 4 && lc < 252 && cs * 248 + 4 * (ln - 1) < G.W;
@@ -421,9 +423,17 @@ __device__ __forceinline__ void fused2_body(const float* __restrict__ inL, const
         if (PACK) {
             float m = st_m1;
             unsigned int c = st_c2;
-            for (int o = G.lpw >> 1; o > 0; o >>= 1) {
-                m = fmaxf(m, __shfl_xor(m, o, 64));
-                c += (unsigned int)__shfl_xor((int)c, o, 64);
+            if ((G.lpw & (G.lpw - 1)) == 0) {
+                for (int o = G.lpw >> 1; o > 0; o >>= 1) {
+                    m = fmaxf(m, __shfl_xor(m, o, 64));
+                    c += (unsigned int)__shfl_xor((int)c, o, 64);
+                }
+            } else {
+                for (int o = 1; o < G.lpw; ++o) {
+                    const int src = min(lane + o, 63);
+                    m = fmaxf(m, __shfl(st_m1, src, 64));
+                    c += (unsigned int)__shfl((int)st_c2, src, 64);
+                }
             }
             c = c > 9u * st_nmm ? c - 9u * st_nmm : 0u;
             if (pj == 0 && writes) {

@@ -47,7 +47,7 @@ struct StripGeom {
     int nwg;                  // ceil(nstrips / 4) workgroups of 4 waves
     int chunk;                // ceil(nwg / 8): workgroups per XCD
     int qcap;                 // near-tie LDS queue capacity in use (<= kWaveQueueCap; tests shrink it)
-    int lpw, wpr;             // packed mode (W < 256, W | 256): lanes per world row (W/4), worlds per wave row
+    int lpw, wpr;             // packed mode (W < 256): lanes per world row (W/4), worlds per wave row (64 / lpw)
 };
 
 // streaming accesses of the hot kernel.  The new planes are not read again within the step, so they
@@ -104,8 +104,9 @@ __device__ __forceinline__ float dpp_mov_nb(float src) {
 
 // left / right neighbour values of the lane's 4-column group for one plane
 // HALO: 0 = W == 256 (wrap inside the wave), 1 = W % 256 == 0, 2 = any other W >= 256,
-//       3 = packed: W in {8,...,128} divides 256, a wave row holds 256/W worlds side by side and the
-//           toroidal wrap is a rotation inside each world's group of W/4 lanes (ds_bpermute).
+//       3 = packed: W < 256 (a multiple of 4): a wave row holds 64 / (W/4) worlds side by side and the
+//           toroidal wrap is a rotation inside each world's group of W/4 lanes (ds_bpermute); widths that do
+//           not divide 256 leave the last lanes of the wave idle.
 template <int HALO>
 __device__ __forceinline__ void lr_neighbours(const float4& v, float halo, int lane, int last_lane, float& lnb,
                                               float& rnb, int lsrc = 0, int rsrc = 0) {
@@ -212,12 +213,13 @@ __device__ __forceinline__ void stream_body(const float* __restrict__ inL, const
     // packed mode: `b` is a GROUP of wpr worlds; this lane's world, its column group and the lanes that
     // hold its left / right neighbour columns (rotation inside the world's lane group)
     const int pw = PACK ? lane / G.lpw : 0, pj = PACK ? lane - pw * G.lpw : 0;
-    const int world = PACK ? min(b * G.wpr + pw, G.B - 1) : b;      // lanes of missing worlds shadow the last one
+    // (widths that do not divide 256 leave the last 64 - wpr*lpw lanes without a world: pw == wpr there)
+    const int world = PACK ? min(b * G.wpr + min(pw, G.wpr - 1), G.B - 1) : b;   // idle lanes shadow a real world
     const int lsrc = PACK ? (pj == 0 ? lane + G.lpw - 1 : lane - 1) : 0;
     const int rsrc = PACK ? (pj == G.lpw - 1 ? lane - (G.lpw - 1) : lane + 1) : 0;
     const int ncq = PACK ? 64 : min(64, (G.W - c0) >> 2);   // active lanes (4 columns each)
     const int last_lane = ncq - 1;
-    const bool active = PACK ? (b * G.wpr + pw < G.B) : lane < ncq;
+    const bool active = PACK ? (pw < G.wpr && b * G.wpr + pw < G.B) : lane < ncq;
     const size_t woff = (size_t)world * G.H * G.W;
     const int colq = PACK ? 4 * pj : c0 + 4 * min(lane, last_lane);   // inactive lanes shadow the last active one
     int hcol = lane < 32 ? c0 - 1 : c0 + 4 * ncq;           // halo column of this lane's half-wave
@@ -334,9 +336,10 @@ __device__ __forceinline__ void stream_body(const float* __restrict__ inL, const
                 size_t wo = woff;
                 int wi = b;
                 if (PACK) {                                 // column i % 256 of the wave row -> (world, column)
-                    wi = b * G.wpr + c / G.W;
-                    c -= (c / G.W) * G.W;
-                    if (wi >= G.B) continue;
+                    const int pwc = c / G.W;
+                    wi = b * G.wpr + pwc;
+                    c -= pwc * G.W;
+                    if (pwc >= G.wpr || wi >= G.B) continue;
                     wo = (size_t)wi * G.H * G.W;
                 }
                 double l9[9], d9[9];
@@ -362,10 +365,19 @@ __device__ __forceinline__ void stream_body(const float* __restrict__ inL, const
     // world of the wave row - a butterfly inside each group of lpw lanes, lpw a power of two)
     if (PACK) {
         float m = acc_max, sl = acc_l, sd = acc_d;
-        for (int o = G.lpw >> 1; o > 0; o >>= 1) {
-            m = fmaxf(m, __shfl_xor(m, o, 64));
-            sl += __shfl_xor(sl, o, 64);
-            sd += __shfl_xor(sd, o, 64);
+        if ((G.lpw & (G.lpw - 1)) == 0) {                       // power-of-two groups: butterfly
+            for (int o = G.lpw >> 1; o > 0; o >>= 1) {
+                m = fmaxf(m, __shfl_xor(m, o, 64));
+                sl += __shfl_xor(sl, o, 64);
+                sd += __shfl_xor(sd, o, 64);
+            }
+        } else {                                                // any group size: the group's first lane gathers
+            for (int o = 1; o < G.lpw; ++o) {
+                const int src = min(lane + o, 63);
+                m = fmaxf(m, __shfl(acc_max, src, 64));
+                sl += __shfl(acc_l, src, 64);
+                sd += __shfl(acc_d, src, 64);
+            }
         }
         if (pj == 0 && active) {
             atomicMax(&stats[world].max_k, (unsigned int)m);
