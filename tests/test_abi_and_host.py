@@ -216,3 +216,15 @@ def test_host_mlp_restores_the_shipped_result_file_g11(golden, tmp_path):
     clone.restore_config(str(again))
     assert np.array_equal(clone.get_parameters(), agent.get_parameters())
     assert sorted(clone.load_config(str(again)).keys()) == ["act_name", "h_dim", "in_dim", "out_dim", "parameters"]
+
+
+def test_tools_and_entry_points_compile():
+    """Every script the docs point at at least parses (they need a GPU to run)."""
+    import glob
+    import os
+    import py_compile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = glob.glob(os.path.join(root, "tools", "*.py")) + [os.path.join(root, n) for n in ("bench.py", "__graft_entry__.py")]
+    assert len(files) >= 12
+    for f in files:
+        py_compile.compile(f, doraise=True, cfile=os.devnull)
