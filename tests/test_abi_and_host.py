@@ -222,9 +222,9 @@ def test_tools_and_entry_points_compile():
     """Every script the docs point at at least parses (they need a GPU to run)."""
     import glob
     import os
-    import py_compile
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     files = glob.glob(os.path.join(root, "tools", "*.py")) + [os.path.join(root, n) for n in ("bench.py", "__graft_entry__.py")]
     assert len(files) >= 12
     for f in files:
-        py_compile.compile(f, doraise=True, cfile=os.devnull)
+        with open(f) as src:
+            compile(src.read(), f, "exec")
