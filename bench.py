@@ -57,7 +57,8 @@ WORKLOADS = {
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=512,
+                    help="timed steps (default 512: the full luminosity ramp BASELINE configs[1] is defined on)")
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--worlds", type=int, default=0, help="override worlds per GPU")
