@@ -59,7 +59,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=512,
                     help="timed steps (default 512: the full luminosity ramp BASELINE configs[1] is defined on)")
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=64)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--worlds", type=int, default=0, help="override worlds per GPU")
     ap.add_argument("--precision", default="fast", choices=["exact", "fast", "f64"],
