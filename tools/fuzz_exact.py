@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Fuzz of the exact mode against the float64 C oracle: random shapes (every kernel family: generic,
 tiled, wave-strip rotate / halo / general / packed, fused pairs), random physics constants in the ranges
-callers use, random luminosity schedules; planes and reductions compared bit for bit after every run.
+callers use, random luminosity schedules, in a fifth of the cases with the LDS queue / mismatch list shrunk so that
+the overflow fallbacks run; planes and reductions compared bit for bit after every run.
 The audit of the tie bound (dw_audit_tie_bound) is evaluated along the way.
 
 usage: fuzz_exact.py [cases=100] [seed=1]"""
@@ -43,6 +44,12 @@ for i in range(cases):
     L0, dL = float(rng.uniform(0.7, 1.5)), float(rng.uniform(-0.01, 0.02))
     p = amd.default_params(B, H, W, 0)
     p.precision = _ffi.PRECISION["exact"]
+    caps = {}
+    if rng.rand() < 0.2:                                # shrink the LDS queue / mismatch list: overflow fallbacks
+        caps = {"DW_TEST_QUEUE_CAP": str(int(rng.choice([1, 4, 16]))), "DW_TEST_MISMATCH_CAP": str(int(rng.choice([0, 1, 2])))}
+    for k in ("DW_TEST_QUEUE_CAP", "DW_TEST_MISMATCH_CAP"):
+        os.environ.pop(k, None)
+    os.environ.update(caps)
     for k, v in over.items():
         setattr(p, k, v)
     eng = amd.Engine(p)
@@ -59,7 +66,7 @@ for i in range(cases):
     ratio = eng.audit_tie_bound(Lg)[1]                  # max float32 error / tie bound over the current state
     worst = max(worst, ratio)
     bad += not same
-    print(("ok  " if same else "FAIL"), i, f"B={B} H={H} W={W} steps={steps} L0={L0:.3f} dL={dL:+.4f} {over} "
+    print(("ok  " if same else "FAIL"), i, f"B={B} H={H} W={W} steps={steps} L0={L0:.3f} dL={dL:+.4f} {over} {caps} "
           f"err/bound={ratio:.3f} :: {eng.kernel_info()[:36]}", flush=True)
     eng.close()
 print(f"{cases - bad}/{cases} cases bit-identical to the float64 oracle; worst float32 error / tie bound = {worst:.3f}")
