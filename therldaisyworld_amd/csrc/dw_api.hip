@@ -84,6 +84,7 @@ struct dw_handle {
     bool use_stream = false;
     StripGeom sgeom{};
     bool allow_fuse = false;          // float32-only mode on wide grids: dw_step_n fuses pairs of steps
+    bool allow_f16 = false;           // dw_step_n keeps the states between its fused launches as binary16 planes
     FusedGeom fgeom{};
     int* done_at = nullptr;           // [B]
     int* agents_done_at = nullptr;    // [B][N]
@@ -312,6 +313,7 @@ static void select_kernel(dw_handle* h) {
             if (v >= 0 && v < kMismatchCap) mcap = v;
         }
         h->allow_fuse = !std::getenv("DW_NO_FUSE");
+        h->allow_f16 = !std::getenv("DW_NO_F16");
         FusedGeom& f = h->fgeom;
         f.B = p.batch; f.H = p.height; f.W = p.width;
         f.SR = g.SR;
@@ -484,8 +486,10 @@ static int launch_forward(dw_handle* h, double L) {
 // Two steps (luminosities L1 then L2) in one launch: float32-only mode, wide grids, no agent update in
 // between.  The buffer that held the input now holds the state TWO steps back, so the retained
 // "previous state" is not valid afterwards; dw_step_n always ends with an ordinary single step.
+// in16 / out16: the input / output planes are binary16 (intermediate states of one dw_step_n run, which
+// live in the same two plane buffers; a quantised state is exact in binary16).  Never with pstats.
 static int launch_forward_fused2(dw_handle* h, double L1, double L2, unsigned int* pstats = nullptr,
-                                 float thr_hi = 0.f) {
+                                 float thr_hi = 0.f, bool in16 = false, bool out16 = false) {
     const dw_params& p = h->prm;
     const int in = h->cur, out = 1 - h->cur;
     PhysF32 P1, P2;
@@ -496,19 +500,47 @@ static int launch_forward_fused2(dw_handle* h, double L1, double L2, unsigned in
     const FusedGeom& g = h->fgeom;
     const dim3 grid((unsigned)g.chunk * 8u);
     const bool rot = p.width == 256, pack = p.width < 256;
+    NEED(!pstats || (!in16 && !out16), DW_EINVAL, "internal: step pairs with world flags run on float32 planes");
     if (p.precision == DW_PRECISION_EXACT) {
         const FusedExactArgs A{h->L32[in], h->D32[in], h->L32[out], h->D32[out], g, P1, lum_part(P2), zero_me, zero_n,
                                pstats, thr_hi, make_f64(p, L1), L1, L2};
-#define DW_FX(R, P, S) hipLaunchKernelGGL((step_stream_fused2_exact<R, P, S>), grid, dim3(256), 0, h->stream, A)
-        if (pstats) { if (pack) DW_FX(true, true, true); else if (rot) DW_FX(true, false, true); else DW_FX(false, false, true); }
-        else { if (pack) DW_FX(true, true, false); else if (rot) DW_FX(true, false, false); else DW_FX(false, false, false); }
+#define DW_FX(R, P, S, TI, TO) \
+    hipLaunchKernelGGL((step_stream_fused2_exact<R, P, S, TI, TO>), grid, dim3(256), 0, h->stream, A)
+#define DW_FX_FMT(R, P)                                                     \
+    do {                                                                    \
+        if (!in16 && !out16) DW_FX(R, P, false, float, float);              \
+        else if (!in16) DW_FX(R, P, false, float, _Float16);                \
+        else if (out16) DW_FX(R, P, false, _Float16, _Float16);             \
+        else DW_FX(R, P, false, _Float16, float);                           \
+    } while (0)
+        if (pstats) {
+            if (pack) DW_FX(true, true, true, float, float);
+            else if (rot) DW_FX(true, false, true, float, float);
+            else DW_FX(false, false, true, float, float);
+        } else {
+            if (pack) DW_FX_FMT(true, true); else if (rot) DW_FX_FMT(true, false); else DW_FX_FMT(false, false);
+        }
+#undef DW_FX_FMT
 #undef DW_FX
     } else {
-#define DW_FF(R, P, S)                                                                                             \
-    hipLaunchKernelGGL((step_stream_fused2<R, P, S>), grid, dim3(256), 0, h->stream, h->L32[in], h->D32[in], h->L32[out], \
-                       h->D32[out], g, P1, P2, zero_me, zero_n, pstats, thr_hi)
-        if (pstats) { if (pack) DW_FF(true, true, true); else if (rot) DW_FF(true, false, true); else DW_FF(false, false, true); }
-        else { if (pack) DW_FF(true, true, false); else if (rot) DW_FF(true, false, false); else DW_FF(false, false, false); }
+#define DW_FF(R, P, S, TI, TO)                                                                                     \
+    hipLaunchKernelGGL((step_stream_fused2<R, P, S, TI, TO>), grid, dim3(256), 0, h->stream, h->L32[in], h->D32[in], \
+                       h->L32[out], h->D32[out], g, P1, P2, zero_me, zero_n, pstats, thr_hi)
+#define DW_FF_FMT(R, P)                                                     \
+    do {                                                                    \
+        if (!in16 && !out16) DW_FF(R, P, false, float, float);              \
+        else if (!in16) DW_FF(R, P, false, float, _Float16);                \
+        else if (out16) DW_FF(R, P, false, _Float16, _Float16);             \
+        else DW_FF(R, P, false, _Float16, float);                           \
+    } while (0)
+        if (pstats) {
+            if (pack) DW_FF(true, true, true, float, float);
+            else if (rot) DW_FF(true, false, true, float, float);
+            else DW_FF(false, false, true, float, float);
+        } else {
+            if (pack) DW_FF_FMT(true, true); else if (rot) DW_FF_FMT(true, false); else DW_FF_FMT(false, false);
+        }
+#undef DW_FF_FMT
 #undef DW_FF
     }
     HIPCHK(hipGetLastError());
@@ -1000,13 +1032,20 @@ int dw_step_n(dw_handle* h, int32_t nsteps, double* L_io, double dL, double min_
         }
         // float32-only mode on wide grids: pairs of steps share one HBM round trip; the last one or two
         // steps are ordinary launches so that the retained previous state is the true predecessor
-        while (nsteps - s0 >= 3) {
+        // The states BETWEEN the fused launches of this call are never seen by anything else: they are kept
+        // as binary16 planes (lossless for a quantised state), which halves the HBM traffic of the run; the
+        // first launch reads and the last one writes float32.
+        const int nfused = (nsteps - s0 - 1) / 2;
+        for (int i = 0; nsteps - s0 >= 3; ++i) {
             const double L1 = L;
             L += dL; L = L > max_L ? max_L : L; L = L < min_L ? min_L : L;
             const double L2 = L;
             L += dL; L = L > max_L ? max_L : L; L = L < min_L ? min_L : L;
-            int rc = launch_forward_fused2(h, L1, L2);
-            if (rc) return rc;
+            int rc = launch_forward_fused2(h, L1, L2, nullptr, 0.f, h->allow_f16 && i > 0, h->allow_f16 && i < nfused - 1);
+            if (rc) {
+                if (h->allow_f16 && i > 0) h->have_state = false;   // the planes hold a binary16 intermediate
+                return rc;
+            }
             s0 += 2;
         }
     }

@@ -31,7 +31,8 @@ struct FusedGeom {
 
 // float64 step-1 value of grid cell (r, c) (any integers: wrapped onto the torus) from the input planes,
 // as a packed light | dark << 16 word
-__device__ inline unsigned int exact1_word(const float* __restrict__ pL, const float* __restrict__ pD, int H, int W,
+template <typename TI>
+__device__ inline unsigned int exact1_word(const TI* __restrict__ pL, const TI* __restrict__ pD, int H, int W,
                                            int r, int c, const PhysF64& Pa) {
     const int rr = ((r % H) + H) % H, cc = ((c % W) + W) % W;
     const int ru = rr == 0 ? H - 1 : rr - 1, rd = rr == H - 1 ? 0 : rr + 1;
@@ -43,7 +44,7 @@ __device__ inline unsigned int exact1_word(const float* __restrict__ pL, const f
 #pragma unroll
         for (int y = 0; y < 3; ++y) {
             const size_t o = (size_t)rows[x] * W + cols[y];
-            w1[x * 3 + y] = (unsigned)pL[o] | ((unsigned)pD[o] << 16);
+            w1[x * 3 + y] = (unsigned)(float)pL[o] | ((unsigned)(float)pD[o] << 16);
         }
     const NewCoverF64 s1 = cell_f64_lean(Pa, w1);
     return (unsigned)dw_round3_k(s1.nl) | ((unsigned)dw_round3_k(s1.nd) << 16);
@@ -52,7 +53,8 @@ __device__ inline unsigned int exact1_word(const float* __restrict__ pL, const f
 // exact two-step value of one cell straight from the input planes, all in float64: nine step-1
 // evaluations (luminosity La) feeding one step-2 evaluation (Lb).  Used only to repair the rare
 // dependents of a float32 step-1 mismatch and as the overflow fallback.
-__device__ inline void exact2_cell(const float* __restrict__ pL, const float* __restrict__ pD, int H, int W, int r,
+template <typename TI>
+__device__ inline void exact2_cell(const TI* __restrict__ pL, const TI* __restrict__ pD, int H, int W, int r,
                                    int c, const PhysF64& Pa, const PhysF64& Pb, float& kl, float& kd) {
     unsigned int w2[9];
 #pragma unroll
@@ -71,7 +73,7 @@ __device__ inline void exact2_cell(const float* __restrict__ pL, const float* __
 #pragma unroll
                 for (int y = 0; y < 3; ++y) {
                     const size_t o = (size_t)rows[x] * W + cols[y];
-                    w1[x * 3 + y] = (unsigned)pL[o] | ((unsigned)pD[o] << 16);
+                    w1[x * 3 + y] = (unsigned)(float)pL[o] | ((unsigned)(float)pD[o] << 16);
                 }
             const NewCoverF64 s1 = cell_f64_lean(Pa, w1);
             w2[a * 3 + e] = (unsigned)dw_round3_k(s1.nl) | ((unsigned)dw_round3_k(s1.nd) << 16);
@@ -103,9 +105,9 @@ constexpr int kMismatchCap = 64;            // float32 step-1 mismatches per wav
 //   pstats[2*world + 1] number of this world's output row groups (4 cells of a lane) holding a step-2
 //                       value above `thr_hi` that cannot be an artefact of float32 or be undone by the few
 //                       cells patched afterwards - a sound lower bound, see agents_lookahead_patch.
-template <bool ROT, bool EXACT, bool PACK = false, bool STATS = false>
-__device__ __forceinline__ void fused2_body(const float* __restrict__ inL, const float* __restrict__ inD,
-                                            float* __restrict__ outL, float* __restrict__ outD, const FusedGeom& G,
+template <bool ROT, bool EXACT, bool PACK = false, bool STATS = false, typename TI = float, typename TO = float>
+__device__ __forceinline__ void fused2_body(const TI* __restrict__ inL, const TI* __restrict__ inD,
+                                            TO* __restrict__ outL, TO* __restrict__ outD, const FusedGeom& G,
                                             const PhysF32& P1, const PhysF32& P2, const PhysF64& P64,
                                             const double& La, const double& Lb,
                                             unsigned long long* __restrict__ zero_me, int zero_n,
@@ -156,8 +158,8 @@ __device__ __forceinline__ void fused2_body(const float* __restrict__ inL, const
         need1[2] = writes;
         need1[3] = writes || wr;
     }
-    const float* pL = inL + woff;
-    const float* pD = inD + woff;
+    const TI* pL = inL + woff;
+    const TI* pD = inD + woff;
 
     auto load_raw = [&](int rr) -> Raw {                        // rr in [r0-2, r0+nr+1], clamped + wrapped
         rr = min(rr, r0 + nr + 1);
@@ -409,8 +411,8 @@ __device__ __forceinline__ void fused2_body(const float* __restrict__ inL, const
                         size_t wo;
                         locate((int)(where >> 16), (int)(where & 0xffffu), wo, gr, gc);
                         const size_t off = wo + (size_t)gr * G.W + gc;
-                        outL[off] = (float)kl;
-                        outD[off] = (float)kd;
+                        outL[off] = (TO)(float)kl;
+                        outD[off] = (TO)(float)kd;
                     }
                 }
                 const unsigned long long mask = __ballot(mism);
@@ -474,8 +476,8 @@ __device__ __forceinline__ void fused2_body(const float* __restrict__ inL, const
                             size_t wo;
                             locate(lrow, lc, wo, gr, gc);
                             const size_t off = wo + (size_t)gr * G.W + gc;
-                            outL[off] = (float)dw_round3_k(o.nl);
-                            outD[off] = (float)dw_round3_k(o.nd);
+                            outL[off] = (TO)(float)dw_round3_k(o.nl);
+                            outD[off] = (TO)(float)dw_round3_k(o.nd);
                         }
                     }
                 }
@@ -492,8 +494,8 @@ __device__ __forceinline__ void fused2_body(const float* __restrict__ inL, const
                 float kl, kd;
                 exact2_cell(inL + wo, inD + wo, G.H, G.W, gr, gc, Pa, Pb, kl, kd);
                 const size_t off = wo + (size_t)gr * G.W + gc;
-                outL[off] = kl;
-                outD[off] = kd;
+                outL[off] = (TO)kl;
+                outD[off] = (TO)kd;
                 if (STATS) {                                     // step-1 maximum from scratch; no step-2 count
                     const unsigned int w1 = exact1_word(inL + wo, inD + wo, G.H, G.W, gr, gc, Pa);
                     atomicMax(&pstats[2 * world_of(lc)], (w1 & 0xffffu) > (w1 >> 16) ? (w1 & 0xffffu) : (w1 >> 16));
@@ -542,7 +544,7 @@ __device__ __forceinline__ void fused2_body(const float* __restrict__ inL, const
     }
 }
 
-template <bool ROT, bool PACK = false, bool STATS = false>
+template <bool ROT, bool PACK = false, bool STATS = false, typename TI = float, typename TO = float>
 __global__ __launch_bounds__(256) void step_stream_fused2(const float* __restrict__ inL, const float* __restrict__ inD,
                                                           float* __restrict__ outL, float* __restrict__ outD,
                                                           FusedGeom G, PhysF32 P1, PhysF32 P2,
@@ -550,15 +552,16 @@ __global__ __launch_bounds__(256) void step_stream_fused2(const float* __restric
                                                           unsigned int* __restrict__ pstats, float thr_hi) {
     const PhysF64 dummy{};
     const double zero = 0.0;
-    fused2_body<ROT, false, PACK, STATS>(inL, inD, outL, outD, G, P1, P2, dummy, zero, zero, zero_me, zero_n, pstats,
-                                         thr_hi);
+    fused2_body<ROT, false, PACK, STATS, TI, TO>(reinterpret_cast<const TI*>(inL), reinterpret_cast<const TI*>(inD),
+                                                 reinterpret_cast<TO*>(outL), reinterpret_cast<TO*>(outD), G, P1, P2, dummy,
+                                                 zero, zero, zero_me, zero_n, pstats, thr_hi);
 }
 
 #ifndef DW_FUSED_EXACT_WAVES
 #define DW_FUSED_EXACT_WAVES 2
 #endif
 struct FusedExactArgs {
-    const float* inL; const float* inD; float* outL; float* outD;
+    const float* inL; const float* inD; float* outL; float* outD;     // float32 or binary16 planes (TI / TO)
     FusedGeom G;
     PhysF32 P1; PhysLumF32 lum2;                                  // step 2 = P1 with these members replaced:
                                                                   // 15 shared constants instead of 2 x 23 (each
@@ -568,13 +571,14 @@ struct FusedExactArgs {
     PhysF64 P64; double La; double Lb;                            // cold (see kernarg_struct)
 };
 
-template <bool ROT, bool PACK = false, bool STATS = false>
+template <bool ROT, bool PACK = false, bool STATS = false, typename TI = float, typename TO = float>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DW_FUSED_EXACT_WAVES, DW_FUSED_EXACT_WAVES)))
 void step_stream_fused2_exact(FusedExactArgs A) {
     const FusedExactArgs& cold = kernarg_struct<FusedExactArgs>();
     const PhysF32 P2 = with_lum(A.P1, A.lum2);
-    fused2_body<ROT, true, PACK, STATS>(A.inL, A.inD, A.outL, A.outD, A.G, A.P1, P2, cold.P64, cold.La, cold.Lb,
-                                        A.zero_me, A.zero_n, A.pstats, A.thr_hi);
+    fused2_body<ROT, true, PACK, STATS, TI, TO>(reinterpret_cast<const TI*>(A.inL), reinterpret_cast<const TI*>(A.inD),
+                                                reinterpret_cast<TO*>(A.outL), reinterpret_cast<TO*>(A.outD), A.G, A.P1, P2,
+                                                cold.P64, cold.La, cold.Lb, A.zero_me, A.zero_n, A.pstats, A.thr_hi);
 }
 
 }  // namespace dw

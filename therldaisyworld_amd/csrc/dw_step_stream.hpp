@@ -71,6 +71,22 @@ __device__ __forceinline__ void stream_store4(float* p, const float4& v) {
 #endif
 }
 
+// binary16 planes (the intermediate states of a dw_step_n run, dw_step_fused.hpp): a quantised state is an
+// integer in [0, 1000], exactly representable in binary16 (integers up to 2048 are), so the conversion
+// is lossless whatever its rounding mode; one v_cvt_pkrtz_f16_f32 packs two cells.
+typedef _Float16 dw_f16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int dw_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float4 stream_load4(const _Float16* p) {
+    const dw_f16x4 v = *reinterpret_cast<const dw_f16x4*>(p);
+    return make_float4((float)v.x, (float)v.y, (float)v.z, (float)v.w);
+}
+__device__ __forceinline__ void stream_store4(_Float16* p, const float4& v) {
+    dw_u32x2 t;
+    t.x = __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_pkrtz(v.x, v.y));
+    t.y = __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_pkrtz(v.z, v.w));
+    __builtin_nontemporal_store(t, reinterpret_cast<dw_u32x2*>(p));
+}
+
 struct Raw {                  // one row as loaded: own 4 columns of both planes + the halo column values
     float4 l, d;
     float hl, hd;             // lanes 0-31: column left of the strip; lanes 32-63: column right of it
