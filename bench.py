@@ -13,7 +13,8 @@ RCCL is used only for the barrier / max-over-ranks timing and a final gather of 
 Arithmetic modes: `fast` (default here) is float32 arithmetic — every cell within one quantum (1e-3) of
 the float64 reference per step, >= 99.5 % identical (tests/test_gpu_parity.py) — and on wide grids
 without agents dw_step_n runs TWO steps per launch (temporal blocking: step-1 rows live only in
-registers), so its algorithmic GB/s can exceed the HBM peak; `exact` (the drop-in class's default) is
+registers) and keeps the states between its launches as binary16 planes (lossless for the quantised
+state), so its algorithmic GB/s can exceed the HBM peak; `exact` (the drop-in class's default) is
 float32 plus a float64 re-evaluation of every near-tie cell and is bit-identical to the float64 reference.
 Both are measured; the one not chosen by --precision is reported under "modes".
 
@@ -288,9 +289,10 @@ def main():
                      "algorithmic_bytes_per_launch": BYTES_PER_CELL_UPDATE * cells * m["steps_per_launch"],
                      "launch_ms": kernel_ms * m["steps_per_launch"], "kernel_ms_per_step": kernel_ms,
                      "f64_fixups_last_step": fixups,
-                     "note": ("two steps share one HBM round trip (temporal blocking in registers): measured traffic "
-                              "is about half the algorithmic bytes, so frac may exceed 1; the fused kernels are "
-                              "VALU-issue-bound (72-74 % busy, profiles/r01e_valu_pmc.json)")
+                     "note": ("two steps share one HBM round trip (temporal blocking in registers) and the states "
+                              "between the launches of a run are binary16 planes (lossless: integers <= 1000): measured "
+                              "traffic is about a quarter of the algorithmic bytes, so frac may exceed 1; the fused "
+                              "kernels are VALU-issue-bound (profiles/r01e_valu_pmc.json)")
                      if m["steps_per_launch"] == 2 else "single-step kernel: HBM-bound"},
     }
     if not args.no_modes:

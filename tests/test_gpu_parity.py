@@ -884,7 +884,7 @@ def test_c1_trajectory_via_episode_kernel_g2(amd, golden):
                                    (2, 3, 256), (1, 5, 500), (1, 65, 260),
                                    (5, 64, 64), (3, 40, 128), (33, 8, 8), (2, 130, 32), (17, 16, 16),   # packed
                                    (3, 70, 96), (5, 20, 100), (2, 66, 192)])          # packed, W does not divide 256
-@pytest.mark.parametrize("nsteps", [3, 8, 13])
+@pytest.mark.parametrize("nsteps", [3, 5, 8, 13])        # 1, 2, 3, 6 fused launches: every float32 / binary16 plane variant
 @pytest.mark.parametrize("precision", ["fast", "exact"])
 def test_fused_step_pairs_equal_single_steps(amd, monkeypatch, B, H, W, nsteps, precision):
     """dw_step_n fuses pairs of steps in one kernel (step_stream_fused2[_exact]): the result must be
@@ -911,6 +911,41 @@ def test_fused_step_pairs_equal_single_steps(amd, monkeypatch, B, H, W, nsteps, 
     for f in ("max_k", "sum_light_k", "sum_dark_k"):
         assert np.array_equal(a[3][f], b[3][f])
     assert np.array_equal(a[4], b[4])
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 100, 256), (1, 70, 320), (9, 40, 64)])
+@pytest.mark.parametrize("precision", ["fast", "exact"])
+def test_binary16_intermediate_planes_are_lossless(amd, monkeypatch, B, H, W, precision):
+    """dw_step_n keeps the states between its fused launches as binary16 planes (every quantised value is
+    an integer <= 1000, exact in binary16): same planes, previous planes and reductions as with float32
+    intermediates (DW_NO_F16), also with the exact mode's overflow fallbacks forced, which patch the
+    binary16 output cell by cell."""
+    monkeypatch.setenv("DW_NO_EPISODE_KERNEL", "1")
+    for caps in (None, ("2", "0")):
+        if caps and precision == "fast":
+            continue
+        outs = []
+        for f16 in (True, False):
+            monkeypatch.delenv("DW_NO_F16", raising=False)
+            if not f16:
+                monkeypatch.setenv("DW_NO_F16", "1")
+            if caps:
+                monkeypatch.setenv("DW_TEST_QUEUE_CAP", caps[0])
+                monkeypatch.setenv("DW_TEST_MISMATCH_CAP", caps[1])
+            eng = _engine(amd, B, H, W, 0, precision)
+            assert ("binary16" in eng.kernel_info()) == f16
+            eng.init_random(11)
+            L = eng.step_n(11, 0.95, 0.006, 0.75, 1.5)
+            outs.append((L, eng.download_planes(), eng.download_planes(1), eng.reduce()))
+            eng.close()
+        monkeypatch.delenv("DW_TEST_QUEUE_CAP", raising=False)
+        monkeypatch.delenv("DW_TEST_MISMATCH_CAP", raising=False)
+        a, b = outs
+        assert a[0] == b[0]
+        assert np.array_equal(a[1][0], b[1][0]) and np.array_equal(a[1][1], b[1][1])
+        assert np.array_equal(a[2][0], b[2][0]) and np.array_equal(a[2][1], b[2][1])
+        for f in ("max_k", "sum_light_k", "sum_dark_k"):
+            assert np.array_equal(a[3][f], b[3][f])
 
 
 def test_fused_fast_trajectory_vs_oracle_tolerance(amd):

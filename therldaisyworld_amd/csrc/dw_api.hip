@@ -1760,8 +1760,9 @@ int dw_kernel_info(dw_handle* h, char* buf, size_t buflen) {
                  g.chunk * 8);
         if (h->allow_fuse) {
             const size_t n = std::strlen(buf);
-            snprintf(buf + n, buflen - n, "; dw_step_n fuses step pairs (step_stream_fused2%s)",
-                     p.precision == DW_PRECISION_EXACT ? "_exact" : "");
+            snprintf(buf + n, buflen - n, "; dw_step_n fuses step pairs (step_stream_fused2%s%s)",
+                     p.precision == DW_PRECISION_EXACT ? "_exact" : "",
+                     h->allow_f16 ? ", binary16 planes between its launches" : "");
         }
     } else if (h->tcq) {
         const int TR = (256 / h->tcq) * h->rpt;

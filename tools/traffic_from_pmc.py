@@ -52,6 +52,10 @@ for prec in ("fast", "exact"):
                  "hbm_bytes_per_cell_update": hbm / (CELLS * steps)}
         if k in stats:
             entry["rocprofv3_kernel_avg_ns"] = float(stats[k]["AverageNs"])
+        if len(names) > 1:                                  # e.g. the float32 / binary16 plane variants of a run
+            entry["variants"] = [{"kernel": n_.split("(")[0], "dispatches": fetch[n_][1],
+                                  "hbm_bytes_per_cell_update": (2.0 * fetch[n_][0] + write[n_][0]) * 1024.0 / (CELLS * steps)}
+                                 for n_ in sorted(names, key=lambda n_: -fetch[n_][1])]
         out[label] = entry
     main = out.get("fused") or out["single"]
     out.update({"kernel": main["kernel"], "steps_per_launch": main["steps_per_launch"],
