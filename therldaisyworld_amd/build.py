@@ -15,8 +15,12 @@ LIB = os.path.join(HERE, "libdaisyworld_hip.so")
 SOURCES = ["dw_api.hip"]
 DEPS = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp"))) + \
        [os.path.join("..", "..", "include", "daisyworld_hip.h")]
+# -fno-slp-vectorize: the float32 map is written in packed form by hand (dw_physics.hpp); what the SLP
+# vectoriser adds on top are packed adds whose operand pairs have to be assembled with v_mov first (the pair
+# sums of a row) - without it the DPP neighbour moves fold into v_add_f32_dpp, the fused kernels lose 5 % of
+# their instructions and the exact ones 35 VGPRs.
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra",
-         "-Wno-unused-parameter"]
+         "-Wno-unused-parameter", "-fno-slp-vectorize"]
 
 
 def _stale() -> bool:

@@ -1,6 +1,7 @@
 // dw_step_fused.hpp — step_stream_fused2[_exact]: two consecutive steps per HBM round trip (temporal
 // blocking inside the wave-strip design; dw_step_n on wide grids without agent updates).
 #pragma once
+#include <type_traits>
 #include "dw_step_stream.hpp"
 
 namespace dw {
@@ -114,7 +115,10 @@ __device__ __forceinline__ void fused2_body(const TI* __restrict__ inL, const TI
                                             unsigned int* __restrict__ pstats = nullptr, float thr_hi = 0.f) {
     // LAG: step 2 runs one row further behind step 1, on results of earlier iterations only (see below).
     // Measured: the exact kernels gain 5-11 %, the float32-only kernels lose 3-11 %.
-    constexpr bool LAG = EXACT;
+#ifndef DW_FUSED_EXACT_LAG
+#define DW_FUSED_EXACT_LAG 1
+#endif
+    constexpr bool LAG = EXACT && DW_FUSED_EXACT_LAG;
     __shared__ uint4 s_queue[EXACT ? 4 * kWaveQueueCap * 3 : 1];
     __shared__ unsigned int s_mm[EXACT ? 4 * kMismatchCap : 1];
     const int bid = blockIdx.x;
@@ -557,9 +561,13 @@ __global__ __launch_bounds__(256) void step_stream_fused2(const float* __restric
                                                  zero, zero, zero_me, zero_n, pstats, thr_hi);
 }
 
-#ifndef DW_FUSED_EXACT_WAVES
-#define DW_FUSED_EXACT_WAVES 2
-#endif
+// Waves per SIMD of the exact kernels: the variant with binary16 planes on both sides (every launch of a long
+// dw_step_n run but the first and the last) fits 3 waves/SIMD (165-168 VGPRs); the others would spill
+// 44-80 B per lane there (measured 30 % slower) and stay at 2.
+template <bool PACK, bool STATS, typename TI, typename TO>
+constexpr int fused_exact_waves() {
+    return (!PACK && !STATS && std::is_same<TI, _Float16>::value && std::is_same<TO, _Float16>::value) ? 3 : 2;
+}
 struct FusedExactArgs {
     const float* inL; const float* inD; float* outL; float* outD;     // float32 or binary16 planes (TI / TO)
     FusedGeom G;
@@ -572,7 +580,8 @@ struct FusedExactArgs {
 };
 
 template <bool ROT, bool PACK = false, bool STATS = false, typename TI = float, typename TO = float>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DW_FUSED_EXACT_WAVES, DW_FUSED_EXACT_WAVES)))
+__global__ __launch_bounds__(256)
+__attribute__((amdgpu_waves_per_eu(fused_exact_waves<PACK, STATS, TI, TO>(), fused_exact_waves<PACK, STATS, TI, TO>())))
 void step_stream_fused2_exact(FusedExactArgs A) {
     const FusedExactArgs& cold = kernarg_struct<FusedExactArgs>();
     const PhysF32 P2 = with_lum(A.P1, A.lum2);
