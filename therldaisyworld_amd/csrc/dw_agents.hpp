@@ -12,7 +12,9 @@ namespace dw {
 // decisions and rewards are bit-identical.  `f64L/f64D` (natural units) are the exact copies of an
 // un-quantised initial state when present (else nullptr).
 // ---------------------------------------------------------------------------------------------
-__global__ void agents_update(float* __restrict__ L32, float* __restrict__ D32,
+// T: float32 planes, or the binary16 planes between the step pairs of one dw_run_episode call.
+template <typename T>
+__global__ void agents_update(T* __restrict__ L32, T* __restrict__ D32,
                               double* __restrict__ f64L, double* __restrict__ f64D,
                               int* __restrict__ idx, double* __restrict__ st,
                               const int* __restrict__ action, int act_b, int act_n, int B, int N,
@@ -39,9 +41,9 @@ __global__ void agents_update(float* __restrict__ L32, float* __restrict__ D32,
                     const size_t o = woff + (size_t)r * W + c;
                     double l, d;
                     if (f64L) { l = f64L[o]; d = f64D[o]; f64L[o] = 0.0; f64D[o] = 0.0; }
-                    else { l = (double)L32[o] / 1000.0; d = (double)D32[o] / 1000.0; }
+                    else { l = (double)(float)L32[o] / 1000.0; d = (double)(float)D32[o] / 1000.0; }
                     s += l + d;
-                    L32[o] = 0.f; D32[o] = 0.f;
+                    L32[o] = (T)0.f; D32[o] = (T)0.f;
                     st[(size_t)b * N + n] = s;
                 }
             }
@@ -124,7 +126,8 @@ __global__ void observe(const PrevT* __restrict__ pL, const PrevT* __restrict__ 
 // ---------------------------------------------------------------------------------------------
 // `agent_mode` (optional, [N]): per agent index 0 = argmax, 1 = argmin, 2 = keep the action already in
 // the buffer (e.g. host-drawn random actions uploaded earlier) — mixed-policy ensembles (BASELINE C5).
-__global__ void policy_greedy(const float* __restrict__ cL, const float* __restrict__ cD,
+template <typename T>
+__global__ void policy_greedy(const T* __restrict__ cL, const T* __restrict__ cD,
                               const int* __restrict__ idx, int B, int N, int H, int W, int mask,
                               int argmin, const int* __restrict__ agent_mode, int* __restrict__ action,
                               int codes = 0) {
@@ -153,7 +156,7 @@ __global__ void policy_greedy(const float* __restrict__ cL, const float* __restr
         if ((mask >> k) & 1) {
             const int r = (ar + (k / 3 - 1) + H) % H, c = (ac + (k % 3 - 1) + W) % W;
             const size_t o = woff + (size_t)r * W + c;
-            v = (double)cL[o] / 1000.0 + (double)cD[o] / 1000.0;
+            v = (double)(float)cL[o] / 1000.0 + (double)(float)cD[o] / 1000.0;
         }
         if (i == 0 || (argmin ? v < bestv : v > bestv)) { best = i; bestv = v; }
     }

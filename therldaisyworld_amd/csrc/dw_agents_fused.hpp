@@ -28,20 +28,21 @@ constexpr int kLookaheadMaxAgents = 64;      // agents per world handled by one 
 
 // float32 step value of grid cell (r, c) (any integers: wrapped onto the torus) of a quantised state, as
 // the step kernels compute it, packed light | dark << 16
-__device__ inline unsigned int fast1_word(const float* __restrict__ pL, const float* __restrict__ pD, int H, int W, int r,
+template <typename TI>
+__device__ inline unsigned int fast1_word(const TI* __restrict__ pL, const TI* __restrict__ pD, int H, int W, int r,
                                           int c, const PhysF32& P) {
     const int rr = ((r % H) + H) % H, cc = ((c % W) + W) % W;
     const int ru = rr == 0 ? H - 1 : rr - 1, rd = rr == H - 1 ? 0 : rr + 1;
     const int cl = cc == 0 ? W - 1 : cc - 1, cr = cc == W - 1 ? 0 : cc + 1;
-    const float* uL = pL + (size_t)ru * W; const float* mL = pL + (size_t)rr * W; const float* dL = pL + (size_t)rd * W;
-    const float* uD = pD + (size_t)ru * W; const float* mD = pD + (size_t)rr * W; const float* dD = pD + (size_t)rd * W;
+    auto at = [&](const TI* p, int row, int col) -> float { return (float)p[(size_t)row * W + col]; };
     // same association as cells4 (exact anyway: the inputs are integers)
-    const float El = (mL[cl] + mL[cr]) + (uL[cc] + dL[cc]);
-    const float Cl = (uL[cl] + uL[cr]) + (dL[cl] + dL[cr]);
-    const float Ed = (mD[cl] + mD[cr]) + (uD[cc] + dD[cc]);
-    const float Cd = (uD[cl] + uD[cr]) + (dD[cl] + dD[cr]);
-    const GrowthF32 g = growth_t<false, float>(P, mL[cc], mD[cc], El, Cl, Ed, Cd);
-    return (unsigned int)finish_fast(mL[cc], g.gql) | ((unsigned int)finish_fast(mD[cc], g.gqd) << 16);
+    const float El = (at(pL, rr, cl) + at(pL, rr, cr)) + (at(pL, ru, cc) + at(pL, rd, cc));
+    const float Cl = (at(pL, ru, cl) + at(pL, ru, cr)) + (at(pL, rd, cl) + at(pL, rd, cr));
+    const float Ed = (at(pD, rr, cl) + at(pD, rr, cr)) + (at(pD, ru, cc) + at(pD, rd, cc));
+    const float Cd = (at(pD, ru, cl) + at(pD, ru, cr)) + (at(pD, rd, cl) + at(pD, rd, cr));
+    const float li = at(pL, rr, cc), di = at(pD, rr, cc);
+    const GrowthF32 g = growth_t<false, float>(P, li, di, El, Cl, Ed, Cd);
+    return (unsigned int)finish_fast(li, g.gql) | ((unsigned int)finish_fast(di, g.gqd) << 16);
 }
 
 // the same map on nine already-evaluated (light | dark << 16) words of a 3x3 block, row-major
@@ -58,8 +59,8 @@ __device__ inline unsigned int fast_word_from9(const unsigned int* w, const Phys
 }
 
 struct LookaheadArgs {
-    const float* inL; const float* inD;          // S0': the state the fused launch read
-    float* outL; float* outD;                    // S2 written by the fused launch, patched here
+    const float* inL; const float* inD;          // S0': the state the fused launch read     } float32 or binary16
+    float* outL; float* outD;                    // S2 written by the fused launch, patched here } planes (TI / TO)
     int* idx; double* st;                        // agents after step t, updated to step t+1
     const signed char* code;                     // [B][N] for step t+1: 0..8 action, -1 greedy argmax, -2 argmin
     unsigned char* agent_ok;                     // [B][N] reward >= 0.1 after step t+1, or null
@@ -73,7 +74,7 @@ struct LookaheadArgs {
     PhysF64 P64; double La, Lb;                  // float64 constants and the two luminosities (exact mode)
 };
 
-template <bool EXACT>
+template <bool EXACT, typename TI = float, typename TO = float>
 __global__ __launch_bounds__(64) void agents_lookahead_patch(LookaheadArgs A) {
     __shared__ unsigned int s_s1[kLookaheadMaxAgents][5];      // S1 at centre, (r,c-1), (r-1,c), (r+1,c), (r,c+1)
     __shared__ int s_act[kLookaheadMaxAgents];
@@ -82,8 +83,10 @@ __global__ __launch_bounds__(64) void agents_lookahead_patch(LookaheadArgs A) {
     const int b = blockIdx.x, lane = threadIdx.x;
     const int N = A.N, H = A.H, W = A.W;
     const size_t woff = (size_t)b * H * W;
-    const float* pL = A.inL + woff;
-    const float* pD = A.inD + woff;
+    const TI* pL = reinterpret_cast<const TI*>(A.inL) + woff;
+    const TI* pD = reinterpret_cast<const TI*>(A.inD) + woff;
+    TO* const oL = reinterpret_cast<TO*>(A.outL);
+    TO* const oD = reinterpret_cast<TO*>(A.outD);
     PhysF64 Pa = A.P64, Pb = A.P64;
     Pa.L = A.La;
     Pb.L = A.Lb;
@@ -183,8 +186,8 @@ __global__ __launch_bounds__(64) void agents_lookahead_patch(LookaheadArgs A) {
             out = fast_word_from9(w2, A.P2);
         }
         const size_t off = woff + (size_t)xr * W + xc;
-        A.outL[off] = (float)(out & 0xffffu);
-        A.outD[off] = (float)(out >> 16);
+        oL[off] = (TO)(float)(out & 0xffffu);
+        oD[off] = (TO)(float)(out >> 16);
     }
 
     // ---- D: the two steps' "biosphere alive" flags ----
@@ -199,7 +202,7 @@ __global__ __launch_bounds__(64) void agents_lookahead_patch(LookaheadArgs A) {
             __threadfence_block();
             __syncthreads();                                     // the patch stores of this block
             float m = 0.f;
-            for (int i = lane; i < H * W; i += 64) m = fmaxf(m, fmaxf(A.outL[woff + i], A.outD[woff + i]));
+            for (int i = lane; i < H * W; i += 64) m = fmaxf(m, fmaxf((float)oL[woff + i], (float)oD[woff + i]));
             m = wave_max(m);
             if (lane == 0) A.alive_t1[b] = m > (float)A.thr ? 1 : 0;
         }

@@ -487,7 +487,7 @@ static int launch_forward(dw_handle* h, double L) {
 // between.  The buffer that held the input now holds the state TWO steps back, so the retained
 // "previous state" is not valid afterwards; dw_step_n always ends with an ordinary single step.
 // in16 / out16: the input / output planes are binary16 (intermediate states of one dw_step_n run, which
-// live in the same two plane buffers; a quantised state is exact in binary16).  Never with pstats.
+// live in the same two plane buffers; a quantised state is exact in binary16).
 static int launch_forward_fused2(dw_handle* h, double L1, double L2, unsigned int* pstats = nullptr,
                                  float thr_hi = 0.f, bool in16 = false, bool out16 = false) {
     const dw_params& p = h->prm;
@@ -500,25 +500,22 @@ static int launch_forward_fused2(dw_handle* h, double L1, double L2, unsigned in
     const FusedGeom& g = h->fgeom;
     const dim3 grid((unsigned)g.chunk * 8u);
     const bool rot = p.width == 256, pack = p.width < 256;
-    NEED(!pstats || (!in16 && !out16), DW_EINVAL, "internal: step pairs with world flags run on float32 planes");
     if (p.precision == DW_PRECISION_EXACT) {
         const FusedExactArgs A{h->L32[in], h->D32[in], h->L32[out], h->D32[out], g, P1, lum_part(P2), zero_me, zero_n,
                                pstats, thr_hi, make_f64(p, L1), L1, L2};
 #define DW_FX(R, P, S, TI, TO) \
     hipLaunchKernelGGL((step_stream_fused2_exact<R, P, S, TI, TO>), grid, dim3(256), 0, h->stream, A)
-#define DW_FX_FMT(R, P)                                                     \
+#define DW_FX_FMT(R, P, S)                                                  \
     do {                                                                    \
-        if (!in16 && !out16) DW_FX(R, P, false, float, float);              \
-        else if (!in16) DW_FX(R, P, false, float, _Float16);                \
-        else if (out16) DW_FX(R, P, false, _Float16, _Float16);             \
-        else DW_FX(R, P, false, _Float16, float);                           \
+        if (!in16 && !out16) DW_FX(R, P, S, float, float);                  \
+        else if (!in16) DW_FX(R, P, S, float, _Float16);                    \
+        else if (out16) DW_FX(R, P, S, _Float16, _Float16);                 \
+        else DW_FX(R, P, S, _Float16, float);                               \
     } while (0)
         if (pstats) {
-            if (pack) DW_FX(true, true, true, float, float);
-            else if (rot) DW_FX(true, false, true, float, float);
-            else DW_FX(false, false, true, float, float);
+            if (pack) DW_FX_FMT(true, true, true); else if (rot) DW_FX_FMT(true, false, true); else DW_FX_FMT(false, false, true);
         } else {
-            if (pack) DW_FX_FMT(true, true); else if (rot) DW_FX_FMT(true, false); else DW_FX_FMT(false, false);
+            if (pack) DW_FX_FMT(true, true, false); else if (rot) DW_FX_FMT(true, false, false); else DW_FX_FMT(false, false, false);
         }
 #undef DW_FX_FMT
 #undef DW_FX
@@ -526,19 +523,17 @@ static int launch_forward_fused2(dw_handle* h, double L1, double L2, unsigned in
 #define DW_FF(R, P, S, TI, TO)                                                                                     \
     hipLaunchKernelGGL((step_stream_fused2<R, P, S, TI, TO>), grid, dim3(256), 0, h->stream, h->L32[in], h->D32[in], \
                        h->L32[out], h->D32[out], g, P1, P2, zero_me, zero_n, pstats, thr_hi)
-#define DW_FF_FMT(R, P)                                                     \
+#define DW_FF_FMT(R, P, S)                                                  \
     do {                                                                    \
-        if (!in16 && !out16) DW_FF(R, P, false, float, float);              \
-        else if (!in16) DW_FF(R, P, false, float, _Float16);                \
-        else if (out16) DW_FF(R, P, false, _Float16, _Float16);             \
-        else DW_FF(R, P, false, _Float16, float);                           \
+        if (!in16 && !out16) DW_FF(R, P, S, float, float);                  \
+        else if (!in16) DW_FF(R, P, S, float, _Float16);                    \
+        else if (out16) DW_FF(R, P, S, _Float16, _Float16);                 \
+        else DW_FF(R, P, S, _Float16, float);                               \
     } while (0)
         if (pstats) {
-            if (pack) DW_FF(true, true, true, float, float);
-            else if (rot) DW_FF(true, false, true, float, float);
-            else DW_FF(false, false, true, float, float);
+            if (pack) DW_FF_FMT(true, true, true); else if (rot) DW_FF_FMT(true, false, true); else DW_FF_FMT(false, false, true);
         } else {
-            if (pack) DW_FF_FMT(true, true); else if (rot) DW_FF_FMT(true, false); else DW_FF_FMT(false, false);
+            if (pack) DW_FF_FMT(true, true, false); else if (rot) DW_FF_FMT(true, false, false); else DW_FF_FMT(false, false, false);
         }
 #undef DW_FF_FMT
 #undef DW_FF
@@ -553,7 +548,8 @@ static int launch_forward_fused2(dw_handle* h, double L1, double L2, unsigned in
     return DW_OK;
 }
 
-static int launch_agents(dw_handle* h, const int* d_action, int act_b, int act_n, bool standalone = false) {
+static int launch_agents(dw_handle* h, const int* d_action, int act_b, int act_n, bool standalone = false,
+                         bool f16 = false) {
     const dw_params& p = h->prm;
     if (p.n_agents == 0) return DW_OK;
     NEED(h->have_state, DW_ESTATE, "no state uploaded");
@@ -562,10 +558,16 @@ static int launch_agents(dw_handle* h, const int* d_action, int act_b, int act_n
          "collision_mode=1: call dw_update_agents, apply the collision pass (it consumes the caller's RNG) to the "
          "downloaded agent states, upload them, then dw_step without actions");
     const int blocks = (p.batch + 63) / 64;
-    hipLaunchKernelGGL(agents_update, dim3(blocks), dim3(64), 0, h->stream, h->L32[h->cur],
-                       h->D32[h->cur], h->f64 == F64_CUR ? h->L64 : nullptr,
-                       h->f64 == F64_CUR ? h->D64 : nullptr, h->idx, h->st, d_action, act_b, act_n,
-                       p.batch, p.n_agents, p.height, p.width, p.agent_gamma, p.collision_mode == 0 ? 1 : 0);
+    if (f16)                                       // binary16 planes between the step pairs of an episode run
+        hipLaunchKernelGGL(agents_update<_Float16>, dim3(blocks), dim3(64), 0, h->stream,
+                           reinterpret_cast<_Float16*>(h->L32[h->cur]), reinterpret_cast<_Float16*>(h->D32[h->cur]),
+                           (double*)nullptr, (double*)nullptr, h->idx, h->st, d_action, act_b, act_n,
+                           p.batch, p.n_agents, p.height, p.width, p.agent_gamma, p.collision_mode == 0 ? 1 : 0);
+    else
+        hipLaunchKernelGGL(agents_update<float>, dim3(blocks), dim3(64), 0, h->stream, h->L32[h->cur],
+                           h->D32[h->cur], h->f64 == F64_CUR ? h->L64 : nullptr,
+                           h->f64 == F64_CUR ? h->D64 : nullptr, h->idx, h->st, d_action, act_b, act_n,
+                           p.batch, p.n_agents, p.height, p.width, p.agent_gamma, p.collision_mode == 0 ? 1 : 0);
     HIPCHK(hipGetLastError());
     return DW_OK;
 }
@@ -1252,7 +1254,7 @@ int dw_policy_greedy(dw_handle* h, int mode) {
     NEED(mode == DW_POLICY_ARGMAX || mode == DW_POLICY_ARGMIN, DW_EINVAL, "bad policy mode");
     NEED(h->cur_quantised || h->f64 != F64_CUR, DW_ESTATE,
          "device policy on an exact float64 initial state is not supported; compute the action on the host");
-    hipLaunchKernelGGL(policy_greedy, dim3((bn + 255) / 256), dim3(256), 0, h->stream, h->L32[h->cur], h->D32[h->cur],
+    hipLaunchKernelGGL(policy_greedy<float>, dim3((bn + 255) / 256), dim3(256), 0, h->stream, h->L32[h->cur], h->D32[h->cur],
                        h->idx, p.batch, p.n_agents, p.height, p.width, p.obs_mask, mode == DW_POLICY_ARGMIN ? 1 : 0,
                        (const int*)nullptr, h->action);
     HIPCHK(hipGetLastError());
@@ -1275,7 +1277,7 @@ int dw_policy_per_agent(dw_handle* h, const int32_t* agent_mode) {
     std::vector<int> m(p.n_agents);
     for (int n = 0; n < p.n_agents; ++n) m[n] = agent_mode[n] == DW_POLICY_TABLE ? 2 : agent_mode[n];
     HIPCHK(hipMemcpyAsync(h->action_tmp, m.data(), sizeof(int) * p.n_agents, hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(policy_greedy, dim3((bn + 255) / 256), dim3(256), 0, h->stream, h->L32[h->cur], h->D32[h->cur],
+    hipLaunchKernelGGL(policy_greedy<float>, dim3((bn + 255) / 256), dim3(256), 0, h->stream, h->L32[h->cur], h->D32[h->cur],
                        h->idx, p.batch, p.n_agents, p.height, p.width, p.obs_mask, 0, h->action_tmp, h->action);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->stream));      // `m` is a local host buffer
@@ -1493,6 +1495,21 @@ static int run_episode_stepwise(dw_handle* h, int32_t nsteps, const double* L_sc
     // With per-step world flags the fused launch also reduces what the flags of both steps need (STATS
     // variants: exact step-1 maximum, count of certain step-2 values above the threshold).
     unsigned int* pstats = world_alive ? reinterpret_cast<unsigned int*>(h->ep_buf + o_ps) : nullptr;
+    // Between consecutive step pairs of this call the planes are binary16 (as in dw_step_n: lossless for the
+    // quantised state, half the traffic of the fused launches); `cur16` says what the current buffer holds.
+    // The pair before an ordinary step writes float32, so the call always ends on float32 planes.
+    bool cur16 = false;
+    auto greedy = [&](int argmin, int codes) {
+        const dim3 g((unsigned)((bn + 255) / 256));
+        if (cur16)
+            hipLaunchKernelGGL(policy_greedy<_Float16>, g, dim3(256), 0, h->stream,
+                               reinterpret_cast<const _Float16*>(h->L32[h->cur]),
+                               reinterpret_cast<const _Float16*>(h->D32[h->cur]), h->idx, B, N, p.height, p.width,
+                               p.obs_mask, argmin, (const int*)nullptr, h->action, codes);
+        else
+            hipLaunchKernelGGL(policy_greedy<float>, g, dim3(256), 0, h->stream, h->L32[h->cur], h->D32[h->cur], h->idx,
+                               B, N, p.height, p.width, p.obs_mask, argmin, (const int*)nullptr, h->action, codes);
+    };
     for (size_t t = 0; t < K; ++t) {
         const bool pair = may_pair && h->cur_quantised && K - t >= 3;
         if (bn && policy_mode != kPolicySkipAgents) {
@@ -1500,27 +1517,26 @@ static int run_episode_stepwise(dw_handle* h, int32_t nsteps, const double* L_sc
             if (from_table) {
                 hipLaunchKernelGGL(actions_from_table, dim3((unsigned)((bn + 255) / 256)), dim3(256), 0, h->stream,
                                    reinterpret_cast<const signed char*>(h->ep_buf + o_tab + t * bn), (int)bn, h->action);
-                hipLaunchKernelGGL(policy_greedy, dim3((unsigned)((bn + 255) / 256)), dim3(256), 0, h->stream,
-                                   h->L32[h->cur], h->D32[h->cur], h->idx, B, N, p.height, p.width, p.obs_mask, 0,
-                                   (const int*)nullptr, h->action, 1);      // codes -1 / -2: greedy / anti-greedy
+                greedy(0, 1);                                               // codes -1 / -2: greedy / anti-greedy
             } else if (policy_mode == DW_POLICY_ZEROS) {
                 HIPCHK(hipMemsetAsync(h->action, 0, sizeof(int) * bn, h->stream));
             } else {
-                hipLaunchKernelGGL(policy_greedy, dim3((unsigned)((bn + 255) / 256)), dim3(256), 0, h->stream,
-                                   h->L32[h->cur], h->D32[h->cur], h->idx, B, N, p.height, p.width, p.obs_mask,
-                                   policy_mode == DW_POLICY_ARGMIN ? 1 : 0, (const int*)nullptr, h->action);
+                greedy(policy_mode == DW_POLICY_ARGMIN ? 1 : 0, 0);
             }
             HIPCHK(hipGetLastError());
-            int rc = launch_agents(h, h->action, B, N);
-            if (rc) return rc;
+            int rc = launch_agents(h, h->action, B, N, false, cur16);
+            if (rc) { if (cur16) h->have_state = false; return rc; }
         }
         if (pair) {
             hipLaunchKernelGGL(agent_flags, dim3((unsigned)((bn + 255) / 256)), dim3(256), 0, h->stream, h->st, (int)bn,
                                h->ep_buf + o_ok + t * bn);
             const double L1 = L_schedule[t], L2 = L_schedule[t + 1];
             if (pstats) HIPCHK(hipMemsetAsync(pstats, 0, sizeof(unsigned int) * 2 * B, h->stream));
-            int rc = launch_forward_fused2(h, L1, L2, pstats, (float)threshold_k);
-            if (rc) return rc;
+            const bool in16 = cur16;
+            const bool out16 = h->allow_f16 && K - (t + 2) >= 3;           // the next two steps are a pair again
+            int rc = launch_forward_fused2(h, L1, L2, pstats, (float)threshold_k, in16, out16);
+            if (rc) { if (in16) h->have_state = false; return rc; }
+            cur16 = out16;
             // codes of step t+1: the caller's table slice, or one byte value for the whole ensemble
             const bool tab2 = policy_mode == DW_POLICY_TABLE || (use_table && use_table[t + 1]);
             unsigned char* codes = h->ep_buf + o_code;
@@ -1543,14 +1559,22 @@ static int run_episode_stepwise(dw_handle* h, int32_t nsteps, const double* L_sc
             A.agent_gamma = p.agent_gamma;
             A.P1 = derive_f32(p, L1); A.P2 = derive_f32(p, L2);
             A.P64 = make_f64(p, L1); A.La = L1; A.Lb = L2;
-            if (p.precision == DW_PRECISION_EXACT)
-                hipLaunchKernelGGL((agents_lookahead_patch<true>), dim3((unsigned)B), dim3(64), 0, h->stream, A);
-            else
-                hipLaunchKernelGGL((agents_lookahead_patch<false>), dim3((unsigned)B), dim3(64), 0, h->stream, A);
+#define DW_LA(E, TI, TO) hipLaunchKernelGGL((agents_lookahead_patch<E, TI, TO>), dim3((unsigned)B), dim3(64), 0, h->stream, A)
+#define DW_LA_FMT(E)                                              \
+    do {                                                          \
+        if (!in16 && !out16) DW_LA(E, float, float);              \
+        else if (!in16) DW_LA(E, float, _Float16);                \
+        else if (out16) DW_LA(E, _Float16, _Float16);             \
+        else DW_LA(E, _Float16, float);                           \
+    } while (0)
+            if (p.precision == DW_PRECISION_EXACT) DW_LA_FMT(true); else DW_LA_FMT(false);
+#undef DW_LA_FMT
+#undef DW_LA
             HIPCHK(hipGetLastError());
             ++t;                                             // two steps done
             continue;
         }
+        NEED(!cur16, DW_EINVAL, "internal: ordinary step on binary16 planes");
         int rc = launch_forward(h, L_schedule[t]);
         if (rc) return rc;
         hipLaunchKernelGGL(episode_flags, dim3((unsigned)((nflag + 255) / 256)), dim3(256), 0, h->stream,
