@@ -761,14 +761,15 @@ def test_run_episode_matches_stepwise_engine(amd, B, H, W):
 @pytest.mark.parametrize("B,H,W,N", [(3, 64, 256, 5), (2, 130, 520, 3), (6, 32, 64, 4), (33, 8, 8, 6), (1, 70, 320, 16)])
 @pytest.mark.parametrize("precision", ["exact", "fast"])
 @pytest.mark.parametrize("policy", ["argmax", "argmin_with_random_steps", "mixed_table"])
-def test_agent_step_pairs_equal_single_steps(amd, monkeypatch, B, H, W, N, precision, policy):
+@pytest.mark.parametrize("K", [5, 11])       # 2 / 5 pairs: float32 -> binary16 -> (binary16 ->)* float32 planes
+def test_agent_step_pairs_equal_single_steps(amd, monkeypatch, B, H, W, N, precision, policy, K):
     """dw_run_episode without per-step world flags runs step PAIRS as one fused launch and patches the
     agents' in-between step in (policy from recomputed step-1 values, grazing in agent order, 3x3 blocks
     around the grazed cells recomputed): planes, agents, per-step agent flags, reductions, observations and
     the retained previous state equal K ordinary steps bit for bit - crowded 8x8 worlds (agents meet on
-    cells), packed and wide grids, greedy / anti-greedy / random / per-agent mixes."""
+    cells), packed and wide grids, greedy / anti-greedy / random / per-agent mixes.  Between consecutive pairs
+    the planes are binary16 (policy, grazing and the patch read and write them as such)."""
     from therldaisyworld_amd import _ffi
-    K = 11
     rng = np.random.RandomState(B * 7 + N)
     use, table, mode = None, None, _ffi.POLICY_ARGMAX
     if policy == "argmin_with_random_steps":
