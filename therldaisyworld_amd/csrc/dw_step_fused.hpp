@@ -127,7 +127,7 @@ __device__ __forceinline__ void fused2_body(const TI* __restrict__ inL, const TI
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
     if (wg == 0)
         for (int i = tid; i < zero_n; i += 256) zero_me[i] = 0ull;
-    const int s = wg * 4 + wv;
+    const int s = __builtin_amdgcn_readfirstlane(wg * 4 + wv);   // wave-uniform: row addressing goes to the scalar unit
     if (s >= G.nstrips) return;
     uint4* q = s_queue + (EXACT ? wv * kWaveQueueCap * 3 : 0);
     unsigned int* mm = s_mm + (EXACT ? wv * kMismatchCap : 0);

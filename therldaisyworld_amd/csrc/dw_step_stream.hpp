@@ -217,7 +217,7 @@ __device__ __forceinline__ void stream_body(const float* __restrict__ inL, const
     if (wg == 0)
         for (int i = tid; i < zero_n; i += 256) zero_me[i] = 0ull;
     uint4* q = s_queue + (EXACT ? wv * kWaveQueueCap * 3 : 0);
-    const int s = wg * 4 + wv;                                  // this wave's strip
+    const int s = __builtin_amdgcn_readfirstlane(wg * 4 + wv);   // this wave's strip (wave-uniform: row addressing on the scalar unit)
     if (s >= G.nstrips) return;                                 // waves are independent: no barrier anywhere
     const int spw = G.nrs * G.ncs;
     const int b = s / spw;
