@@ -134,12 +134,14 @@ def _advance_host_scalars(env, executed):
     env._invalidate()
 
 
-def _mlp_chunks(env, params, member_a, member_b, half, max_steps, chunk, stop_after):
+def _mlp_chunks(env, params, member_a, member_b, half, max_steps, chunk, after_chunk):
     """The step loop shared by the two fitness harnesses: chunks of steps device-resident
-    (``dw_run_episode_mlp``), the reference's per-step float64 bookkeeping done by `stop_after(reward,
-    done) -> bool` on the downloaded (B,N,1) rewards / done flags in step order.  When the episode ends
-    inside a chunk, the chunk is replayed from a device-side snapshot for exactly the executed steps, so
-    the environment is left where the reference's loop leaves it."""
+    (``dw_run_episode_mlp``), the reference's per-step float64 bookkeeping done by `after_chunk(rewards,
+    dones) -> (executed, finished)` on the downloaded (K,B,N,1) rewards (already `reward * (reward > 0)`) and
+    done flags of the chunk: it accounts for the steps up to and including the one that ends the episode, with
+    every float64 sum accumulated in step order.  When the episode ends inside a chunk, the chunk is replayed
+    from a device-side snapshot for exactly the executed steps, so the environment is left where the
+    reference's loop leaves it."""
     eng = env._engine
     first, finished = True, False
     while not finished and env.step_count < max_steps:
@@ -149,11 +151,7 @@ def _mlp_chunks(env, params, member_a, member_b, half, max_steps, chunk, stop_af
         if K > 1:
             eng.snapshot_save()
         rewards, dones = eng.run_episode_mlp(Ls, params, member_a, member_b, half, env._L_pass)
-        executed = K
-        for t in range(K):
-            if stop_after(rewards[t] * (rewards[t] > 0), dones[t]):
-                executed, finished = t + 1, True
-                break
+        executed, finished = after_chunk(rewards * (rewards > 0), dones)
         if executed < K:
             eng.snapshot_restore()
             eng.run_episode_mlp(Ls[:executed], params, member_a, member_b, half, env._L_pass)
@@ -175,14 +173,20 @@ def get_fitness(env, agent, adversary, max_steps=768, chunk=64):
     member_a, member_b = np.zeros(B, dtype=np.int32), np.ones(B, dtype=np.int32)
     acc = {"done_at": np.zeros((B, N, 1), dtype=int), "total_steps": 0, "sum_reward": 0.0}
 
-    def stop_after(reward, done):
-        all_done = (np.ones_like(done).sum() - done.sum()) == 0
-        acc["done_at"] += (1 - 1 * done)
-        acc["sum_reward"] += (reward[:, :half]).mean()
-        acc["total_steps"] = acc["total_steps"] + (1 - 1 * done)
-        return all_done
+    def after_chunk(rewards, dones):
+        # ref :160-176 per step: all_done, done_at += 1 - done, sum_reward += mean of the agents' half,
+        # total_steps += 1 - done; the loop leaves after the step in which every agent is done
+        K = rewards.shape[0]
+        ended = np.nonzero(dones.reshape(K, -1).all(axis=1))[0]
+        executed = int(ended[0]) + 1 if ended.size else K
+        alive = (1 - 1 * dones[:executed]).sum(axis=0)                    # integers: any order
+        acc["done_at"] += alive
+        acc["total_steps"] = acc["total_steps"] + alive
+        means = [rewards[t][:, :half].mean() for t in range(executed)]    # the reference's call, step by step
+        acc["sum_reward"] = np.add.accumulate(np.array([acc["sum_reward"]] + means))[-1]   # added in step order
+        return executed, ended.size > 0
 
-    _mlp_chunks(env, params, member_a, member_b, half, max_steps, chunk, stop_after)
+    _mlp_chunks(env, params, member_a, member_b, half, max_steps, chunk, after_chunk)
     fitness = acc["sum_reward"] / (B * N)
     return fitness, acc["total_steps"], acc["done_at"].tolist()
 
@@ -214,17 +218,28 @@ def get_fitness_population(env, population, adversary_of=None, worlds_per_member
     sum_reward = np.zeros(P)
     running = np.ones(P, dtype=bool)
 
-    def stop_after(reward, done):
-        live = np.repeat(running, worlds_per_member)[:, None, None]
-        done_at[...] += live * (1 - 1 * done)
-        total_steps[...] += live * (1 - 1 * done)
-        r = reward.reshape(P, worlds_per_member, N, 1)
-        d = done.reshape(P, worlds_per_member, N, 1)
-        sum_reward[...] += running * r[:, :, :half].mean(axis=(1, 2, 3))
-        running[...] &= ~d.reshape(P, -1).all(axis=1)
-        return not running.any()
+    def after_chunk(rewards, dones):
+        # per step and member (get_fitness's loop on the member's block of worlds): while the member runs,
+        # done_at / total_steps += 1 - done and sum_reward += mean reward of its agents' half; the member stops
+        # after the step in which all its agents are done; the ensemble stops when no member runs
+        K = rewards.shape[0]
+        all_done = dones.reshape(K, P, -1).all(axis=2)                                 # (K,P)
+        earlier = np.zeros((K, P), dtype=bool)
+        earlier[1:] = np.logical_or.accumulate(all_done, axis=0)[:-1]
+        run_t = running[None, :] & ~earlier                                            # running DURING step t
+        none_left = np.nonzero(~(run_t & ~all_done).any(axis=1))[0]
+        executed = int(none_left[0]) + 1 if none_left.size else K
+        live = np.repeat(run_t[:executed], worlds_per_member, axis=1)[:, :, None, None]
+        alive = (live * (1 - 1 * dones[:executed])).sum(axis=0)                        # integers: any order
+        done_at[...] += alive
+        total_steps[...] += alive
+        means = np.stack([rewards[t].reshape(P, worlds_per_member, N, 1)[:, :, :half].mean(axis=(1, 2, 3))
+                          for t in range(executed)])                                   # the same call, step by step
+        sum_reward[...] = np.add.accumulate(np.concatenate([sum_reward[None], run_t[:executed] * means]), axis=0)[-1]
+        running[...] = run_t[executed - 1] & ~all_done[executed - 1]
+        return executed, none_left.size > 0
 
-    _mlp_chunks(env, params, member, adv_member, half, max_steps, chunk, stop_after)
+    _mlp_chunks(env, params, member, adv_member, half, max_steps, chunk, after_chunk)
     fitness = sum_reward / (worlds_per_member * N)
     return [(fitness[m], total_steps[m * worlds_per_member:(m + 1) * worlds_per_member],
              done_at[m * worlds_per_member:(m + 1) * worlds_per_member].tolist()) for m in range(P)]
