@@ -18,7 +18,8 @@ __global__ void agents_update(T* __restrict__ L32, T* __restrict__ D32,
                               double* __restrict__ f64L, double* __restrict__ f64D,
                               int* __restrict__ idx, double* __restrict__ st,
                               const int* __restrict__ action, int act_b, int act_n, int B, int N,
-                              int H, int W, double agent_gamma, int do_clip) {
+                              int H, int W, double agent_gamma, int do_clip,
+                              double* __restrict__ reward = nullptr, unsigned char* __restrict__ done = nullptr) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     const size_t woff = (size_t)b * H * W;
@@ -53,6 +54,13 @@ __global__ void agents_update(T* __restrict__ L32, T* __restrict__ D32,
         for (int n = 0; n < N; ++n) {                                            // ref :244
             const double s = st[(size_t)b * N + n];
             st[(size_t)b * N + n] = s < 0.0 ? 0.0 : (s > 1.0 ? 1.0 : s);
+        }
+    if (reward)      // the step's reward / done (ref step :486-492; the physics pass does not touch the stores)
+        for (int n = 0; n < N; ++n) {
+            const double s = st[(size_t)b * N + n];
+            const double r = s * (s > 0.0 ? 1.0 : 0.0);
+            reward[(size_t)b * N + n] = r;
+            done[(size_t)b * N + n] = r < 0.1 ? 1 : 0;
         }
 }
 
@@ -177,7 +185,8 @@ __global__ void policy_greedy(const T* __restrict__ cL, const T* __restrict__ cD
 // activations travel through LDS.  ~130 dependent float64 fmas per agent instead of 1808 in one thread.
 __global__ __launch_bounds__(64) void policy_mlp(const double* __restrict__ obs, const double* __restrict__ W,
                                                  const int* __restrict__ member, int B, int N, int a0, int a1,
-                                                 int* __restrict__ action) {
+                                                 int* __restrict__ action, const int* __restrict__ member_hi = nullptr,
+                                                 int split = -1) {
     __shared__ double s_x[4][64], s_h1[4][16], s_h2[4][32], s_o[4][16];
     const int na = a1 - a0;
     const int g = threadIdx.x >> 4, j = threadIdx.x & 15;
@@ -186,7 +195,9 @@ __global__ __launch_bounds__(64) void policy_mlp(const double* __restrict__ obs,
     const int tc = valid ? t : 0;
     const int b = tc / na, n = a0 + (tc - b * na);
     const double* x = obs + ((size_t)b * N + n) * 63;
-    if (member) W += (size_t)member[b] * 1808;
+    // split >= 0: agents [split, N) take their parameter set from member_hi (agent / adversary halves in one launch)
+    const int* mm = (split >= 0 && n >= split) ? member_hi : member;
+    if (mm) W += (size_t)mm[b] * 1808;
     const double* W1 = W;                 // [63][16]
     const double* W2 = W + 63 * 16;       // [16][32]
     const double* W3 = W2 + 16 * 32;      // [32][9]

@@ -549,7 +549,7 @@ static int launch_forward_fused2(dw_handle* h, double L1, double L2, unsigned in
 }
 
 static int launch_agents(dw_handle* h, const int* d_action, int act_b, int act_n, bool standalone = false,
-                         bool f16 = false) {
+                         bool f16 = false, double* d_reward = nullptr, unsigned char* d_done = nullptr) {
     const dw_params& p = h->prm;
     if (p.n_agents == 0) return DW_OK;
     NEED(h->have_state, DW_ESTATE, "no state uploaded");
@@ -562,12 +562,14 @@ static int launch_agents(dw_handle* h, const int* d_action, int act_b, int act_n
         hipLaunchKernelGGL(agents_update<_Float16>, dim3(blocks), dim3(64), 0, h->stream,
                            reinterpret_cast<_Float16*>(h->L32[h->cur]), reinterpret_cast<_Float16*>(h->D32[h->cur]),
                            (double*)nullptr, (double*)nullptr, h->idx, h->st, d_action, act_b, act_n,
-                           p.batch, p.n_agents, p.height, p.width, p.agent_gamma, p.collision_mode == 0 ? 1 : 0);
+                           p.batch, p.n_agents, p.height, p.width, p.agent_gamma, p.collision_mode == 0 ? 1 : 0,
+                           d_reward, d_done);
     else
         hipLaunchKernelGGL(agents_update<float>, dim3(blocks), dim3(64), 0, h->stream, h->L32[h->cur],
                            h->D32[h->cur], h->f64 == F64_CUR ? h->L64 : nullptr,
                            h->f64 == F64_CUR ? h->D64 : nullptr, h->idx, h->st, d_action, act_b, act_n,
-                           p.batch, p.n_agents, p.height, p.width, p.agent_gamma, p.collision_mode == 0 ? 1 : 0);
+                           p.batch, p.n_agents, p.height, p.width, p.agent_gamma, p.collision_mode == 0 ? 1 : 0,
+                           d_reward, d_done);
     HIPCHK(hipGetLastError());
     return DW_OK;
 }
@@ -1399,20 +1401,15 @@ int dw_run_episode_mlp(dw_handle* h, int32_t nsteps, const double* L_schedule, c
     for (size_t t = 0; t < K; ++t) {
         int rc = observe_into_scratch(h, L_init, 0);
         if (rc) return rc;
-        if (split > 0)
-            hipLaunchKernelGGL(policy_mlp, dim3((unsigned)((B * split + 3) / 4)), dim3(64), 0, h->stream, h->scratch, d_w,
-                               d_ma, B, N, 0, split, h->action);
-        if (split < N)
-            hipLaunchKernelGGL(policy_mlp, dim3((unsigned)((B * (N - split) + 3) / 4)), dim3(64), 0, h->stream, h->scratch,
-                               d_w, d_mb, B, N, split, N, h->action);
+        // both halves in one launch (agents [split, N) read member_b), reward / done written by the grazing
+        // kernel: 4 instead of 6 launches per step - the loop is bound by the host thread that issues them
+        hipLaunchKernelGGL(policy_mlp, dim3((unsigned)((bn + 3) / 4)), dim3(64), 0, h->stream, h->scratch, d_w, d_ma, B, N,
+                           0, N, h->action, d_mb, split);
         HIPCHK(hipGetLastError());
-        rc = launch_agents(h, h->action, B, N);
+        rc = launch_agents(h, h->action, B, N, false, false, d_r + t * bn, d_d + t * bn);
         if (rc) return rc;
         rc = launch_forward(h, L_schedule[t]);
         if (rc) return rc;
-        hipLaunchKernelGGL(reward_done, dim3((unsigned)((bn + 255) / 256)), dim3(256), 0, h->stream, h->st, d_r + t * bn,
-                           d_d + t * bn, (int)bn);
-        HIPCHK(hipGetLastError());
     }
     if (reward) HIPCHK(hipMemcpyAsync(reward, d_r, sizeof(double) * K * bn, hipMemcpyDeviceToHost, h->stream));
     if (done) HIPCHK(hipMemcpyAsync(done, d_d, K * bn, hipMemcpyDeviceToHost, h->stream));
