@@ -85,11 +85,18 @@ template <typename PrevT, bool POST>
 __global__ void observe(const PrevT* __restrict__ pL, const PrevT* __restrict__ pD,
                         const float* __restrict__ cL, const float* __restrict__ cD,
                         const int* __restrict__ idx, const double* __restrict__ st, int B, int N,
-                        int H, int W, PhysF64 P, int mask, double* __restrict__ obs) {
+                        int H, int W, PhysF64 P, int mask, double* __restrict__ obs,
+                        double* __restrict__ reward = nullptr, unsigned char* __restrict__ done = nullptr) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= B * N * 9) return;
     const int k = gid % 9, an = gid / 9;       // patch cell, flat agent id
     const int b = an / N;
+    if (reward && k == 0) {                    // the step's reward / done ride along (ref step :486-492)
+        const double s = st[an];
+        const double r = s * (s > 0.0 ? 1.0 : 0.0);
+        reward[an] = r;
+        done[an] = r < 0.1 ? 1 : 0;
+    }
     double* o7 = obs + (size_t)an * 63 + k;    // channel stride 9
     if (!((mask >> k) & 1)) {
 #pragma unroll

@@ -120,7 +120,7 @@ static int run_episode_impl(dw_handle* h, int32_t nsteps, const double* L_schedu
                             const uint8_t* use_table, const int8_t* table, uint32_t threshold_k,
                             uint8_t* world_alive, uint8_t* agent_ok);
 static bool episode_kernel_applies(const dw_handle* h);
-static int observe_into_scratch(dw_handle* h, double L_init, size_t extra_bytes);
+static int observe_into_scratch(dw_handle* h, double L_init, size_t extra_bytes, bool reward_tail = false);
 
 static int ensure_scratch(dw_handle* h, size_t bytes) {
     if (h->scratch_bytes >= bytes) return DW_OK;
@@ -1199,12 +1199,9 @@ int dw_env_step(dw_handle* h, const int32_t* action, int32_t action_b, int32_t a
         // observations, rewards and done flags land in ONE device block [obs | reward | done] and come back in
         // one copy (each extra copy costs its own ~5-10 us of latency on a 90 us step)
         const size_t d_rew = sizeof(double) * bn * 63, d_done = d_rew + sizeof(double) * bn, d_total = d_done + bn;
-        rc = observe_into_scratch(h, L, d_total - d_rew + 64);
+        rc = observe_into_scratch(h, L, d_total - d_rew + 64, true);     // reward | done written by the same kernel
         if (rc) return rc;
         unsigned char* blk = reinterpret_cast<unsigned char*>(h->scratch);
-        hipLaunchKernelGGL(reward_done, dim3((unsigned)((bn + 255) / 256)), dim3(256), 0, h->stream, h->st,
-                           reinterpret_cast<double*>(blk + d_rew), blk + d_done, (int)bn);
-        HIPCHK(hipGetLastError());
         if (big_obs) {
             if (obs) HIPCHK(hipMemcpyAsync(obs, blk, d_rew, hipMemcpyDeviceToHost, h->stream));
             HIPCHK(hipMemcpyAsync(h->pinned + o_rew, blk + d_rew, d_total - d_rew, hipMemcpyDeviceToHost, h->stream));
@@ -1287,11 +1284,14 @@ int dw_policy_per_agent(dw_handle* h, const int32_t* agent_mode) {
 }
 
 // fills h->scratch with the [B][N][63] observations of the current state (device side of dw_get_obs)
-static int observe_into_scratch(dw_handle* h, double L_init, size_t extra_bytes) {
+// reward_tail: the kernel also writes [reward (B,N) float64 | done (B,N) u8] right behind the observations
+static int observe_into_scratch(dw_handle* h, double L_init, size_t extra_bytes, bool reward_tail) {
     const dw_params& p = h->prm;
     const size_t bn = (size_t)p.batch * p.n_agents;
     int rc = ensure_scratch(h, sizeof(double) * bn * 63 + extra_bytes);
     if (rc) return rc;
+    double* d_rew = reward_tail ? h->scratch + bn * 63 : nullptr;
+    unsigned char* d_done = reward_tail ? reinterpret_cast<unsigned char*>(h->scratch + bn * 64) : nullptr;
     const int threads = (int)(bn * 9);
     const dim3 g((threads + 127) / 128);
     const int cur = h->cur, prev = 1 - h->cur;
@@ -1300,21 +1300,21 @@ static int observe_into_scratch(dw_handle* h, double L_init, size_t extra_bytes)
         if (h->f64 == F64_PREV)
             hipLaunchKernelGGL((observe<double, true>), g, dim3(128), 0, h->stream, h->L64, h->D64, h->L32[cur],
                                h->D32[cur], h->idx, h->st, p.batch, p.n_agents, p.height, p.width, P, p.obs_mask,
-                               h->scratch);
+                               h->scratch, d_rew, d_done);
         else
             hipLaunchKernelGGL((observe<float, true>), g, dim3(128), 0, h->stream, h->L32[prev], h->D32[prev],
                                h->L32[cur], h->D32[cur], h->idx, h->st, p.batch, p.n_agents, p.height, p.width, P,
-                               p.obs_mask, h->scratch);
+                               p.obs_mask, h->scratch, d_rew, d_done);
     } else {
         const PhysF64 P = make_f64(p, L_init);
         if (h->f64 == F64_CUR)
             hipLaunchKernelGGL((observe<double, false>), g, dim3(128), 0, h->stream, h->L64, h->D64, h->L32[cur],
                                h->D32[cur], h->idx, h->st, p.batch, p.n_agents, p.height, p.width, P, p.obs_mask,
-                               h->scratch);
+                               h->scratch, d_rew, d_done);
         else
             hipLaunchKernelGGL((observe<float, false>), g, dim3(128), 0, h->stream, h->L32[cur], h->D32[cur],
                                h->L32[cur], h->D32[cur], h->idx, h->st, p.batch, p.n_agents, p.height, p.width, P,
-                               p.obs_mask, h->scratch);
+                               p.obs_mask, h->scratch, d_rew, d_done);
     }
     HIPCHK(hipGetLastError());
     return DW_OK;
