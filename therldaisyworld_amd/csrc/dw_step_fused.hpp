@@ -11,8 +11,12 @@ namespace dw {
 // update between the steps: dw_step_n on wide grids).  Temporal blocking inside the wave-strip
 // design: as a wave marches down its strip, every new input row yields one row of step-1 results
 // (kept only in a second 3-row register window, never written to memory) and, one row behind it,
-// one row of step-2 results, which is stored.  HBM traffic per cell-update drops to ~8.5 B
+// one row of step-2 results, which is stored.  HBM traffic per cell-update drops to 8.25 B
 // (measured by PMC, profiles/), and the kernel becomes VALU-bound.
+// TI / TO: plane element type on the input / output side - float, or _Float16 for the states between
+// the launches of one dw_step_n / dw_run_episode call, which nothing else reads: a quantised state is
+// an integer <= 1000, exact in binary16 (4.13 B per cell-update).  The first launch of a run reads and
+// the last one writes float32.
 //
 // Horizontal neighbours of step-1 results come from adjacent lanes by DPP like the inputs do.
 //   ROT (W == 256): the wave spans the whole torus row, all 64 lanes produce output.
@@ -98,6 +102,8 @@ constexpr int kMismatchCap = 64;            // float32 step-1 mismatches per wav
 // cone was uncertain.  Queue / mismatch-list overflow: the whole strip is recomputed in float64.
 // Fused launches leave the per-world reductions untouched (dw_step_n always ends with a single step,
 // which recomputes them), they only keep the double-buffer protocol.
+// LAG (exact kernels): step 2 runs one row further behind step 1, so that the two row maps of an iteration
+// are independent (see the loop below).
 // PACK (with ROT): narrow worlds (W | 256) side by side in the wave row, as in step_stream<halo=packed>:
 // every lane has its own world, the horizontal wrap is a rotation inside the world's lane group, and a
 // local column lc of the wave row decodes to (world, column) = (lc / W, lc % W).
