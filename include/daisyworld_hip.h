@@ -187,7 +187,11 @@ int dw_download_actions(dw_handle* h, int32_t* action /* [B][N] */);
 /* `nsteps` consecutive steps with the reference's luminosity recurrence L <- clamp(L + dL)
  * (ref :471-473) evaluated on the host in float64, *L_io updated.  use_device_actions: 0 = no
  * update_agents call at all (ref `action is None` with n_agents == 0), 1 = actions are taken from
- * the device action buffer every step (constant unless a policy refreshes it). */
+ * the device action buffer every step (constant unless a policy refreshes it).
+ * The result equals `nsteps` calls of dw_step bit for bit; how the steps are issued is the library's business
+ * (on wide grids two steps share one launch, and the states between the launches of one call live as binary16
+ * planes - lossless for the quantised state; everything any other entry point reads is float32 again when the
+ * call returns). */
 int dw_step_n(dw_handle* h, int32_t nsteps, double* L_io, double dL, double min_L, double max_L,
               int use_device_actions);
 
