@@ -228,3 +228,76 @@ def test_tools_and_entry_points_compile():
     for f in files:
         with open(f) as src:
             compile(src.read(), f, "exec")
+
+
+def _random_episode(rng, K, B, N, p_done):
+    """Rewards / done flags of K steps whose agents die for good, one after the other."""
+    dead = np.zeros((B, N, 1), dtype=bool)
+    rewards, dones = np.zeros((K, B, N, 1)), np.zeros((K, B, N, 1), dtype=bool)
+    for t in range(K):
+        dead |= rng.rand(B, N, 1) < p_done
+        r = np.round(rng.rand(B, N, 1), 3) * ~dead
+        rewards[t], dones[t] = r, r < 0.1
+    return rewards, dones
+
+
+@pytest.mark.parametrize("chunk", [1, 5, 64])
+@pytest.mark.parametrize("p_done", [0.0, 0.02, 0.2])
+def test_fitness_bookkeeping_per_chunk_equals_the_reference_loop(chunk, p_done):
+    """harness._fitness_chunk / _population_chunk account a chunk of steps at once; the result (float64 sums
+    accumulated in step order, integer counters, stopping step) equals the reference's per-step statements
+    (daisy/evo/sges.py:160-176) whatever the chunking."""
+    from therldaisyworld_amd import harness
+    rng = np.random.RandomState(int(chunk * 100 + p_done * 1000))
+    K, P, wpm, N = 40, 3, 4, 4
+    B, half = P * wpm, N // 2
+    rewards, dones = _random_episode(rng, K, B, N, p_done)
+    # --- reference loop, one world block (get_fitness) ---
+    done_at, total, sum_reward, steps = np.zeros((B, N, 1), dtype=int), 0, 0.0, 0
+    for t in range(K):
+        reward, done = rewards[t], dones[t]
+        all_done = (np.ones_like(done).sum() - done.sum()) == 0
+        done_at += (1 - 1 * done)
+        sum_reward += (reward[:, :half]).mean()
+        total = total + (1 - 1 * done)
+        steps += 1
+        if all_done:
+            break
+    acc = {"done_at": np.zeros((B, N, 1), dtype=int), "total_steps": 0, "sum_reward": 0.0}
+    got, t0 = 0, 0
+    while t0 < K:
+        e, fin = harness._fitness_chunk(acc, rewards[t0:t0 + chunk], dones[t0:t0 + chunk], half)
+        got += e
+        if fin:
+            break
+        t0 += chunk
+    assert got == steps and acc["sum_reward"] == sum_reward
+    assert np.array_equal(acc["done_at"], done_at) and np.array_equal(acc["total_steps"], total)
+    # --- reference loop per member on its own block of worlds (get_fitness_population) ---
+    want = []
+    for m in range(P):
+        sl = slice(m * wpm, (m + 1) * wpm)
+        d_at, tot, s, n = np.zeros((wpm, N, 1), dtype=int), np.zeros((wpm, N, 1), dtype=int), 0.0, 0
+        for t in range(K):
+            reward, done = rewards[t][sl], dones[t][sl]
+            d_at += (1 - 1 * done)
+            tot += (1 - 1 * done)
+            s += reward[:, :half].mean()
+            n += 1
+            if done.all():
+                break
+        want.append((d_at, tot, s, n))
+    acc = {"done_at": np.zeros((B, N, 1), dtype=int), "total_steps": np.zeros((B, N, 1), dtype=int),
+           "sum_reward": np.zeros(P), "running": np.ones(P, dtype=bool)}
+    got, t0 = 0, 0
+    while t0 < K:
+        e, fin = harness._population_chunk(acc, rewards[t0:t0 + chunk], dones[t0:t0 + chunk], half, wpm)
+        got += e
+        if fin:
+            break
+        t0 += chunk
+    assert got == max(w[3] for w in want)
+    for m, (d_at, tot, s, n) in enumerate(want):
+        sl = slice(m * wpm, (m + 1) * wpm)
+        assert np.array_equal(acc["done_at"][sl], d_at) and np.array_equal(acc["total_steps"][sl], tot)
+        assert acc["sum_reward"][m] == s

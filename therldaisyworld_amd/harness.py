@@ -159,6 +159,48 @@ def _mlp_chunks(env, params, member_a, member_b, half, max_steps, chunk, after_c
         first = False
 
 
+def _fitness_chunk(acc, rewards, dones, half):
+    """Bookkeeping of `get_fitness` for one chunk of K steps (rewards (K,B,N,1) = reward * (reward > 0), dones
+    (K,B,N,1) bool), equal to the reference's per-step statements (daisy/evo/sges.py:160-176: all_done,
+    done_at += 1 - done, sum_reward += mean reward of the agents' half, total_steps += 1 - done; the loop
+    leaves after the step in which every agent is done).  Returns (steps accounted for, episode ended)."""
+    K = rewards.shape[0]
+    ended = np.nonzero(dones.reshape(K, -1).all(axis=1))[0]
+    executed = int(ended[0]) + 1 if ended.size else K
+    alive = (1 - 1 * dones[:executed]).sum(axis=0)                    # integers: any order
+    acc["done_at"] += alive
+    acc["total_steps"] = acc["total_steps"] + alive
+    means = [rewards[t][:, :half].mean() for t in range(executed)]    # the reference's call, step by step
+    acc["sum_reward"] = np.add.accumulate(np.array([acc["sum_reward"]] + means))[-1]   # added in step order
+    return executed, ended.size > 0
+
+
+def _population_chunk(acc, rewards, dones, half, worlds_per_member):
+    """The same for a population evaluated as one ensemble (member m owns worlds [m*wpm, (m+1)*wpm)): while a
+    member runs, done_at / total_steps += 1 - done and sum_reward[m] += mean reward of its agents' half; the
+    member stops after the step in which all ITS agents are done; the ensemble stops when no member runs.
+    acc: done_at, total_steps (B,N,1) int, sum_reward (P,) float64, running (P,) bool - updated in place."""
+    K, B, N = rewards.shape[0], rewards.shape[1], rewards.shape[2]
+    P = B // worlds_per_member
+    running = acc["running"]
+    all_done = dones.reshape(K, P, -1).all(axis=2)                                 # (K,P)
+    earlier = np.zeros((K, P), dtype=bool)
+    earlier[1:] = np.logical_or.accumulate(all_done, axis=0)[:-1]
+    run_t = running[None, :] & ~earlier                                            # running DURING step t
+    none_left = np.nonzero(~(run_t & ~all_done).any(axis=1))[0]
+    executed = int(none_left[0]) + 1 if none_left.size else K
+    live = np.repeat(run_t[:executed], worlds_per_member, axis=1)[:, :, None, None]
+    alive = (live * (1 - 1 * dones[:executed])).sum(axis=0)                        # integers: any order
+    acc["done_at"][...] += alive
+    acc["total_steps"][...] += alive
+    means = np.stack([rewards[t].reshape(P, worlds_per_member, N, 1)[:, :, :half].mean(axis=(1, 2, 3))
+                      for t in range(executed)])                                   # the same call, step by step
+    acc["sum_reward"][...] = np.add.accumulate(np.concatenate([acc["sum_reward"][None], run_t[:executed] * means]),
+                                               axis=0)[-1]                         # added in step order
+    running[...] = run_t[executed - 1] & ~all_done[executed - 1]
+    return executed, none_left.size > 0
+
+
 def get_fitness(env, agent, adversary, max_steps=768, chunk=64):
     """ref SimpleGaussianES.get_fitness (daisy/evo/sges.py:144-181): one episode in which the first half
     of every world's agents is driven by `agent` and the second half by `adversary` (both MLP policies);
@@ -172,21 +214,8 @@ def get_fitness(env, agent, adversary, max_steps=768, chunk=64):
     params = np.stack([agent.get_parameters(), adversary.get_parameters()])
     member_a, member_b = np.zeros(B, dtype=np.int32), np.ones(B, dtype=np.int32)
     acc = {"done_at": np.zeros((B, N, 1), dtype=int), "total_steps": 0, "sum_reward": 0.0}
-
-    def after_chunk(rewards, dones):
-        # ref :160-176 per step: all_done, done_at += 1 - done, sum_reward += mean of the agents' half,
-        # total_steps += 1 - done; the loop leaves after the step in which every agent is done
-        K = rewards.shape[0]
-        ended = np.nonzero(dones.reshape(K, -1).all(axis=1))[0]
-        executed = int(ended[0]) + 1 if ended.size else K
-        alive = (1 - 1 * dones[:executed]).sum(axis=0)                    # integers: any order
-        acc["done_at"] += alive
-        acc["total_steps"] = acc["total_steps"] + alive
-        means = [rewards[t][:, :half].mean() for t in range(executed)]    # the reference's call, step by step
-        acc["sum_reward"] = np.add.accumulate(np.array([acc["sum_reward"]] + means))[-1]   # added in step order
-        return executed, ended.size > 0
-
-    _mlp_chunks(env, params, member_a, member_b, half, max_steps, chunk, after_chunk)
+    _mlp_chunks(env, params, member_a, member_b, half, max_steps, chunk,
+                lambda rewards, dones: _fitness_chunk(acc, rewards, dones, half))
     fitness = acc["sum_reward"] / (B * N)
     return fitness, acc["total_steps"], acc["done_at"].tolist()
 
@@ -218,28 +247,9 @@ def get_fitness_population(env, population, adversary_of=None, worlds_per_member
     sum_reward = np.zeros(P)
     running = np.ones(P, dtype=bool)
 
-    def after_chunk(rewards, dones):
-        # per step and member (get_fitness's loop on the member's block of worlds): while the member runs,
-        # done_at / total_steps += 1 - done and sum_reward += mean reward of its agents' half; the member stops
-        # after the step in which all its agents are done; the ensemble stops when no member runs
-        K = rewards.shape[0]
-        all_done = dones.reshape(K, P, -1).all(axis=2)                                 # (K,P)
-        earlier = np.zeros((K, P), dtype=bool)
-        earlier[1:] = np.logical_or.accumulate(all_done, axis=0)[:-1]
-        run_t = running[None, :] & ~earlier                                            # running DURING step t
-        none_left = np.nonzero(~(run_t & ~all_done).any(axis=1))[0]
-        executed = int(none_left[0]) + 1 if none_left.size else K
-        live = np.repeat(run_t[:executed], worlds_per_member, axis=1)[:, :, None, None]
-        alive = (live * (1 - 1 * dones[:executed])).sum(axis=0)                        # integers: any order
-        done_at[...] += alive
-        total_steps[...] += alive
-        means = np.stack([rewards[t].reshape(P, worlds_per_member, N, 1)[:, :, :half].mean(axis=(1, 2, 3))
-                          for t in range(executed)])                                   # the same call, step by step
-        sum_reward[...] = np.add.accumulate(np.concatenate([sum_reward[None], run_t[:executed] * means]), axis=0)[-1]
-        running[...] = run_t[executed - 1] & ~all_done[executed - 1]
-        return executed, none_left.size > 0
-
-    _mlp_chunks(env, params, member, adv_member, half, max_steps, chunk, after_chunk)
+    acc = {"done_at": done_at, "total_steps": total_steps, "sum_reward": sum_reward, "running": running}
+    _mlp_chunks(env, params, member, adv_member, half, max_steps, chunk,
+                lambda rewards, dones: _population_chunk(acc, rewards, dones, half, worlds_per_member))
     fitness = sum_reward / (worlds_per_member * N)
     return [(fitness[m], total_steps[m * worlds_per_member:(m + 1) * worlds_per_member],
              done_at[m * worlds_per_member:(m + 1) * worlds_per_member].tolist()) for m in range(P)]
