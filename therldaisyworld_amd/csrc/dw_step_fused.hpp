@@ -122,11 +122,11 @@ __device__ __forceinline__ void fused2_body(const TI* __restrict__ inL, const TI
     // LAG: step 2 runs one row further behind step 1, on results of earlier iterations only (see below).
     // Measured: the exact kernels gain 5-11 %; of the float32-only kernels the packed
     // one gains 6 % (its neighbour exchange is a ds_bpermute with LDS latency), the overlapped-strip one
-    // 1 %, and the W = 256 one loses 15 % (it drops to 2 waves/SIMD).
+    // 1.5 %, and the W = 256 one loses 10-15 % (also when held at 3 waves/SIMD): all but that one use it.
 #ifndef DW_FUSED_EXACT_LAG
 #define DW_FUSED_EXACT_LAG 1
 #endif
-    constexpr bool LAG = (EXACT && DW_FUSED_EXACT_LAG) || PACK;
+    constexpr bool LAG = (EXACT && DW_FUSED_EXACT_LAG) || PACK || !ROT;
     __shared__ uint4 s_queue[EXACT ? 4 * kWaveQueueCap * 3 : 1];
     __shared__ unsigned int s_mm[EXACT ? 4 * kMismatchCap : 1];
     const int bid = blockIdx.x;
