@@ -102,7 +102,7 @@ constexpr int kMismatchCap = 64;            // float32 step-1 mismatches per wav
 // cone was uncertain.  Queue / mismatch-list overflow: the whole strip is recomputed in float64.
 // Fused launches leave the per-world reductions untouched (dw_step_n always ends with a single step,
 // which recomputes them), they only keep the double-buffer protocol.
-// LAG (exact kernels): step 2 runs one row further behind step 1, so that the two row maps of an iteration
+// LAG (all kernels): step 2 runs one row further behind step 1, so that the two row maps of an iteration
 // are independent (see the loop below).
 // PACK (with ROT): narrow worlds (W | 256) side by side in the wave row, as in step_stream<halo=packed>:
 // every lane has its own world, the horizontal wrap is a rotation inside the world's lane group, and a
@@ -120,13 +120,12 @@ __device__ __forceinline__ void fused2_body(const TI* __restrict__ inL, const TI
                                             unsigned long long* __restrict__ zero_me, int zero_n,
                                             unsigned int* __restrict__ pstats = nullptr, float thr_hi = 0.f) {
     // LAG: step 2 runs one row further behind step 1, on results of earlier iterations only (see below).
-    // Measured: the exact kernels gain 5-11 %; of the float32-only kernels the packed
-    // one gains 6 % (its neighbour exchange is a ds_bpermute with LDS latency), the overlapped-strip one
-    // 1.5 %, and the W = 256 one loses 10-15 % (also when held at 3 waves/SIMD): all but that one use it.
-#ifndef DW_FUSED_EXACT_LAG
-#define DW_FUSED_EXACT_LAG 1
+    // Measured: exact kernels -5...-11 %, packed float32 -6 %, W = 256 float32 -4 %,
+    // overlapped strips -1.5 %.  (-DDW_FUSED_LAG=0 builds the dependent order for comparison.)
+#ifndef DW_FUSED_LAG
+#define DW_FUSED_LAG 1
 #endif
-    constexpr bool LAG = (EXACT && DW_FUSED_EXACT_LAG) || PACK || !ROT;
+    constexpr bool LAG = DW_FUSED_LAG != 0;
     __shared__ uint4 s_queue[EXACT ? 4 * kWaveQueueCap * 3 : 1];
     __shared__ unsigned int s_mm[EXACT ? 4 * kMismatchCap : 1];
     const int bid = blockIdx.x;
@@ -173,14 +172,14 @@ __device__ __forceinline__ void fused2_body(const TI* __restrict__ inL, const TI
     const TI* pL = inL + woff;
     const TI* pD = inD + woff;
 
-    auto load_raw = [&](int rr) -> Raw {                        // rr in [r0-2, r0+nr+1], clamped + wrapped
+    struct RawIn { decltype(stream_load4_raw(pL)) l, d; };      // one row of both planes as loaded (float4 or 4 x binary16)
+    auto load_raw = [&](int rr) -> RawIn {                      // rr in [r0-2, r0+nr+1], clamped + wrapped
         rr = min(rr, r0 + nr + 1);
         rr = rr < 0 ? rr + G.H : rr;
         rr = rr >= G.H ? rr - G.H : rr;
-        Raw w;
-        w.l = stream_load4(pL + (size_t)rr * G.W + col);
-        w.d = stream_load4(pD + (size_t)rr * G.W + col);
-        w.hl = 0.f; w.hd = 0.f;
+        RawIn w;
+        w.l = stream_load4_raw(pL + (size_t)rr * G.W + col);
+        w.d = stream_load4_raw(pD + (size_t)rr * G.W + col);
         return w;
     };
     auto nbrs = [&](const float4& v, float& a, float& c) {
@@ -255,10 +254,10 @@ __device__ __forceinline__ void fused2_body(const TI* __restrict__ inL, const TI
     // windows: IL/ID input rows, SL/SD step-1 rows; slot of row index j (0 = row r0-2) is j % 3
     Row4 IL[3], ID[3], SL[3], SD[3];
     {
-        const Raw p0 = load_raw(r0 - 2), p1 = load_raw(r0 - 1), p2 = load_raw(r0);
-        to_rows4(p0.l, p0.d, IL[0], ID[0]);
-        to_rows4(p1.l, p1.d, IL[1], ID[1]);
-        to_rows4(p2.l, p2.d, IL[2], ID[2]);
+        const RawIn p0 = load_raw(r0 - 2), p1 = load_raw(r0 - 1), p2 = load_raw(r0);
+        to_rows4(widen4(p0.l), widen4(p0.d), IL[0], ID[0]);
+        to_rows4(widen4(p1.l), widen4(p1.d), IL[1], ID[1]);
+        to_rows4(widen4(p2.l), widen4(p2.d), IL[2], ID[2]);
     }
     using U0 = std::integral_constant<int, 0>;
     using U1 = std::integral_constant<int, 1>;
@@ -273,7 +272,7 @@ __device__ __forceinline__ void fused2_body(const TI* __restrict__ inL, const TI
         auto iter = [&](auto U, auto D1, auto D2, int j) {
             constexpr int u = decltype(U)::value;                  // u == j % 3
             constexpr bool do1 = decltype(D1)::value, do2 = decltype(D2)::value;
-            Raw nx;
+            RawIn nx;
             if (do1) nx = load_raw(r0 + j);                        // input row j+2, needed by the NEXT iteration
             __builtin_amdgcn_sched_barrier(0);
             float l1[4], d1[4], l2[4], d2[4];
@@ -300,7 +299,7 @@ __device__ __forceinline__ void fused2_body(const TI* __restrict__ inL, const TI
                 if (STATS && writes && j >= 2 && j <= nr + 1) st_m1 = fmaxf(st_m1, sm1);   // step-1 rows of MY output cells
                 to_rows4(make_float4(l1[0], l1[1], l1[2], l1[3]), make_float4(d1[0], d1[1], d1[2], d1[3]), SL[u], SD[u]);
                 __builtin_amdgcn_sched_barrier(0);
-                to_rows4(nx.l, nx.d, IL[(u + 2) % 3], ID[(u + 2) % 3]);   // input row j+2 replaces input row j-1
+                to_rows4(widen4(nx.l), widen4(nx.d), IL[(u + 2) % 3], ID[(u + 2) % 3]);   // input row j+2 replaces input row j-1
             }
         };
         using Yes = std::true_type;
@@ -326,7 +325,7 @@ __device__ __forceinline__ void fused2_body(const TI* __restrict__ inL, const TI
         // on, output row k = j-3 (local row j-1) from step-1 rows j-2, j-1, j
         auto iter = [&](auto U, int j) {
             constexpr int u = decltype(U)::value;                  // u == j % 3
-            const Raw nx = load_raw(r0 + j);                       // input row j+2, needed by the NEXT iteration
+            const RawIn nx = load_raw(r0 + j);                       // input row j+2, needed by the NEXT iteration
             __builtin_amdgcn_sched_barrier(0);
             float4 l1, d1;
             float sm = 0.f;
@@ -346,7 +345,7 @@ __device__ __forceinline__ void fused2_body(const TI* __restrict__ inL, const TI
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
-            to_rows4(nx.l, nx.d, IL[(u + 2) % 3], ID[(u + 2) % 3]);   // input row j+2 replaces input row j-1
+            to_rows4(widen4(nx.l), widen4(nx.d), IL[(u + 2) % 3], ID[(u + 2) % 3]);   // input row j+2 replaces input row j-1
         };
         const int jend = nr + 2;
         int j = 1;

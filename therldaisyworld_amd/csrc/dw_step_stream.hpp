@@ -80,6 +80,12 @@ __device__ __forceinline__ float4 stream_load4(const _Float16* p) {
     const dw_f16x4 v = *reinterpret_cast<const dw_f16x4*>(p);
     return make_float4((float)v.x, (float)v.y, (float)v.z, (float)v.w);
 }
+// the same load WITHOUT the conversion: the fused kernels keep a prefetched row as loaded and widen it where it
+// is consumed, an iteration later (a conversion placed next to the load would wait for it at once)
+__device__ __forceinline__ dw_f16x4 stream_load4_raw(const _Float16* p) { return *reinterpret_cast<const dw_f16x4*>(p); }
+__device__ __forceinline__ float4 stream_load4_raw(const float* p) { return stream_load4(p); }
+__device__ __forceinline__ float4 widen4(const dw_f16x4& v) { return make_float4((float)v.x, (float)v.y, (float)v.z, (float)v.w); }
+__device__ __forceinline__ float4 widen4(const float4& v) { return v; }
 __device__ __forceinline__ void stream_store4(_Float16* p, const float4& v) {
     dw_u32x2 t;
     t.x = __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_pkrtz(v.x, v.y));
