@@ -292,7 +292,7 @@ def main():
                      "note": ("two steps share one HBM round trip (temporal blocking in registers) and the states "
                               "between the launches of a run are binary16 planes (lossless: integers <= 1000): measured "
                               "traffic is about a quarter of the algorithmic bytes, so frac may exceed 1; the fused "
-                              "kernels are VALU-issue-bound (profiles/r01e_valu_pmc.json)")
+                              "kernels are VALU-issue-bound (83-85 % busy, profiles/r01k_valu_pmc.json)")
                      if m["steps_per_launch"] == 2 else "single-step kernel: HBM-bound"},
     }
     if not args.no_modes:
