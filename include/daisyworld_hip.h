@@ -123,6 +123,10 @@ int dw_get_params(const dw_handle* h, dw_params* out);
 
 const char* dw_last_error(void);
 int dw_abi_version(void);
+/* Hash of the sources + compiler flags this library was built from (16 hex digits; "unknown" for a build
+ * that did not go through therldaisyworld_amd/build.py).  build.py rebuilds when it differs from the
+ * sources in the tree, so a stale binary cannot run under newer host code. */
+const char* dw_build_id(void);
 
 /* ---- state in / out ------------------------------------------------------------------------- */
 

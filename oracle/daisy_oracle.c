@@ -42,8 +42,11 @@ static void daisy_kernel(double k[3][3]) {
         for (int b = 0; b < 3; ++b) k[a][b] /= s;
 }
 
-/* out[i][j] = sum_{a,b} k[a][b] * x[i-(a-1)][j-(b-1)], toroidal. ref: nn/functional.py:12-49 */
-static void conv3x3(const double *x, double *out, int H, int W, const double k[3][3]) {
+/* out[i][j] = sum_{a,b} k[a][b] * x[i-(a-1)][j-(b-1)], toroidal. ref: nn/functional.py:12-49
+ * par != 0: the rows of this ONE world are shared out over the OpenMP threads (few big worlds; every cell
+ * is computed by the same expression either way). */
+static void conv3x3(const double *x, double *out, int H, int W, const double k[3][3], int par) {
+#pragma omp parallel for schedule(static) if (par)
     for (int i = 0; i < H; ++i) {
         for (int j = 0; j < W; ++j) {
             double acc = 0.0;
@@ -73,7 +76,7 @@ static inline double clip01(double x) { return x < 0.0 ? 0.0 : (x > 1.0 ? 1.0 : 
  *                 growth_l, growth_d (un-rounded side-effect caches, ref :345-347,373,415-419)
  */
 static void forward_world(const oracle_params *P, double L, int H, int W, const double *light,
-                          const double *dark, double *out7, double *scratch, double *caches) {
+                          const double *dark, double *out7, double *scratch, double *caches, int par) {
     const size_t n = (size_t)H * W;
     double *bare = scratch, *cb = scratch + n, *cl = scratch + 2 * n, *cd = scratch + 3 * n;
     double *dl = scratch + 4 * n, *dd = scratch + 5 * n;
@@ -83,12 +86,13 @@ static void forward_world(const oracle_params *P, double L, int H, int W, const 
         for (int b = 0; b < 3; ++b) ka[a][b] = (a == 1 && b == 1) ? 0.0 : 1.0 / 8.0; /* ref :280-281 */
 
     for (size_t i = 0; i < n; ++i) bare[i] = P->p - light[i] - dark[i];   /* ref :381 */
-    conv3x3(bare, cb, H, W, ka);                                          /* ref :391-392 */
-    conv3x3(light, cl, H, W, ka);
-    conv3x3(dark, cd, H, W, ka);
-    conv3x3(light, dl, H, W, kd);                                         /* ref :428-429 */
-    conv3x3(dark, dd, H, W, kd);
+    conv3x3(bare, cb, H, W, ka, par);                                     /* ref :391-392 */
+    conv3x3(light, cl, H, W, ka, par);
+    conv3x3(dark, cd, H, W, ka, par);
+    conv3x3(light, dl, H, W, kd, par);                                    /* ref :428-429 */
+    conv3x3(dark, dd, H, W, kd, par);
 
+#pragma omp parallel for schedule(static) if (par)
     for (size_t i = 0; i < n; ++i) {
         /* ref :387-392 */
         double Al = 0.0, A = 0.0;
@@ -129,12 +133,34 @@ static void forward_world(const oracle_params *P, double L, int H, int W, const 
 
 /* ---- exported entry points (ctypes) ------------------------------------------------------ */
 
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+/* fewer worlds than threads and worlds big enough to share out by rows */
+static int few_big_worlds(int B, size_t n) {
+#ifdef _OPENMP
+    return B < omp_get_max_threads() && n >= (size_t)1 << 16;
+#else
+    (void)B; (void)n;
+    return 0;
+#endif
+}
+
 /* forward() for B worlds.  light/dark: [B][H][W] f64.  out7: [B][7][H][W].  caches optional
  * [B][7][H][W].  Returns 0, or -1 on allocation failure. */
 int oracle_forward(const oracle_params *P, double L, int B, int H, int W, const double *light,
                    const double *dark, double *out7, double *caches) {
     const size_t n = (size_t)H * W;
     int rc = 0;
+    if (few_big_worlds(B, n)) {                  /* one world at a time, its rows over the threads */
+        double *scratch = (double *)malloc(sizeof(double) * 8 * n);
+        if (!scratch) return -1;
+        for (int b = 0; b < B; ++b)
+            forward_world(P, L, H, W, light + b * n, dark + b * n, out7 + (size_t)b * 7 * n, scratch,
+                          caches ? caches + (size_t)b * 7 * n : NULL, 1);
+        free(scratch);
+        return 0;
+    }
 #pragma omp parallel
     {
         double *scratch = (double *)malloc(sizeof(double) * 8 * n);
@@ -145,7 +171,7 @@ int oracle_forward(const oracle_params *P, double L, int B, int H, int W, const 
 #pragma omp for schedule(static)
             for (int b = 0; b < B; ++b)
                 forward_world(P, L, H, W, light + b * n, dark + b * n, out7 + (size_t)b * 7 * n,
-                              scratch, caches ? caches + (size_t)b * 7 * n : NULL);
+                              scratch, caches ? caches + (size_t)b * 7 * n : NULL, 0);
             free(scratch);
         }
     }
@@ -160,6 +186,26 @@ int oracle_step_n(const oracle_params *P, double *L_io, double dL, double min_L,
     const size_t n = (size_t)H * W;
     int rc = 0;
     double L_end = *L_io;
+    if (few_big_worlds(B, n)) {
+        double *scratch = (double *)malloc(sizeof(double) * 8 * n);
+        double *out7 = (double *)malloc(sizeof(double) * 7 * n);
+        if (!scratch || !out7) { free(scratch); free(out7); return -1; }
+        for (int b = 0; b < B; ++b) {
+            double L = *L_io;
+            for (int s = 0; s < steps; ++s) {
+                forward_world(P, L, H, W, light + b * n, dark + b * n, out7, scratch, NULL, 1);
+                memcpy(light + b * n, out7 + 1 * n, sizeof(double) * n);
+                memcpy(dark + b * n, out7 + 2 * n, sizeof(double) * n);
+                L += dL;
+                L = L > max_L ? max_L : (L < min_L ? min_L : L);
+            }
+            L_end = L;
+        }
+        free(scratch);
+        free(out7);
+        *L_io = L_end;
+        return 0;
+    }
 #pragma omp parallel
     {
         double *scratch = (double *)malloc(sizeof(double) * 8 * n);
@@ -172,7 +218,7 @@ int oracle_step_n(const oracle_params *P, double *L_io, double dL, double min_L,
             for (int b = 0; b < B; ++b) {
                 double L = *L_io;
                 for (int s = 0; s < steps; ++s) {
-                    forward_world(P, L, H, W, light + b * n, dark + b * n, out7, scratch, NULL);
+                    forward_world(P, L, H, W, light + b * n, dark + b * n, out7, scratch, NULL, 0);
                     memcpy(light + b * n, out7 + 1 * n, sizeof(double) * n);
                     memcpy(dark + b * n, out7 + 2 * n, sizeof(double) * n);
                     L += dL;
@@ -194,7 +240,6 @@ int oracle_step_n(const oracle_params *P, double *L_io, double dL, double min_L,
 int oracle_sizeof_params(void) { return (int)sizeof(oracle_params); }
 
 #ifdef _OPENMP
-#include <omp.h>
 int oracle_max_threads(void) { return omp_get_max_threads(); }
 void oracle_set_threads(int n) { if (n > 0) omp_set_num_threads(n); }
 #else

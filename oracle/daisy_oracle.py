@@ -387,6 +387,39 @@ class OracleDaisyWorld:
         return obs, reward, done, {}
 
 
+class OracleDaisyWorldC(OracleDaisyWorld):
+    """The same environment with the physics pass evaluated by the C restatement (oracle/daisy_oracle.c,
+    pinned against this module and the golden vectors by tests/test_oracle_golden.py) - for parity cases
+    whose grids are too large for the NumPy stencils (1024^2 and up).  Agents, observations, rewards and
+    the luminosity ramp are the Python code above.  The quantised outputs are identical to the NumPy
+    environment's; the un-rounded side-effect caches (and the un-rounded temperature channels of the
+    initial grid) agree to a few 1e-16 relative (pow() against ** 0.25)."""
+
+    def _c_pass(self, grid):
+        from . import c_oracle
+        out, caches = c_oracle.forward(np.ascontiguousarray(grid[:, CH_LIGHT]), np.ascontiguousarray(grid[:, CH_DARK]),
+                                       self.L, c_oracle.OracleParams.from_obj(self.P), want_caches=True)
+        self.temp, self.temp_light, self.temp_dark = caches[:, 0:1], caches[:, 1:2], caches[:, 2:3]
+        self.beta_l, self.beta_d = caches[:, 3:4], caches[:, 4:5]
+        self.growth = caches[:, 5:7]
+        return out
+
+    def _physics(self, grid):
+        self._c_pass(grid)
+        return self.temp, self.temp_light, self.temp_dark, self.growth
+
+    def forward(self, grid):
+        """ref: daisy_world_rl.py:434-461 (physics in C: same staging, same float64 operations)."""
+        P = self.P
+        out = self._c_pass(grid)
+        if P.n_agents:
+            for bb in range(P.batch_size):
+                for nn in range(P.n_agents):
+                    r, c = self.agent_indices[bb, nn, 0], self.agent_indices[bb, nn, 1]
+                    out[bb, CH_TEMP_LIGHT, r, c] = self.agent_states[bb, nn, 0]
+        return out
+
+
 # ----------------------------------------------------------------------------------------------
 # scripted policy  (ref: daisy/agents/greedy.py:5-36)
 # ----------------------------------------------------------------------------------------------

@@ -66,6 +66,9 @@ def test_bad_arguments_are_rejected(built):
     h = C.c_void_p()
     assert lib.dw_create(C.byref(p), C.byref(h)) == _ffi.DW_EINVAL
     assert b"3x3" in lib.dw_last_error()
+    lib.dw_default_params(C.byref(p), 1, 50000, 50000, 0)   # H*W overflows the kernels' int32 cell index
+    assert lib.dw_create(C.byref(p), C.byref(h)) == _ffi.DW_EINVAL
+    assert b"2^31-1" in lib.dw_last_error()
     lib.dw_default_params(C.byref(p), 1, 8, 8, 0)
     p.abi_version = 99
     assert lib.dw_create(C.byref(p), C.byref(h)) == _ffi.DW_EINVAL

@@ -237,6 +237,68 @@ def test_c_oracle_matches_numpy_oracle_multiworld():
     assert np.array_equal(out, ref)
 
 
+def test_c_oracle_row_parallel_mode_equals_world_parallel_mode():
+    """Few big worlds are shared out by rows instead of by worlds (oracle/daisy_oracle.c, few_big_worlds):
+    the same cells by the same expressions."""
+    from oracle import c_oracle
+    rng = np.random.RandomState(4)
+    B, H, W = 2, 256, 256                               # H*W = 2^16 and B < threads: the row-parallel path
+    light = np.rint(rng.rand(B, H, W) * 400) / 1000
+    dark = np.rint(rng.rand(B, H, W) * 400) / 1000
+    nthreads = c_oracle.max_threads()
+    if nthreads < 3:
+        pytest.skip("needs > 2 OpenMP threads to take the row-parallel path")
+    out_rows, caches_rows = c_oracle.forward(light, dark, 1.07, want_caches=True)
+    l1, d1 = light.copy(), dark.copy()
+    La = c_oracle.step_n(l1, d1, 1.07, 0.01, 3)
+    c_oracle.set_threads(1)                             # B >= threads: the world-parallel path
+    try:
+        out_w, caches_w = c_oracle.forward(light, dark, 1.07, want_caches=True)
+        l2, d2 = light.copy(), dark.copy()
+        Lb = c_oracle.step_n(l2, d2, 1.07, 0.01, 3)
+    finally:
+        c_oracle.set_threads(nthreads)
+    assert np.array_equal(out_rows, out_w) and np.array_equal(caches_rows, caches_w)
+    assert La == Lb and np.array_equal(l1, l2) and np.array_equal(d1, d2)
+
+
+def test_c_backed_environment_equals_numpy_environment(golden):
+    """OracleDaisyWorldC (physics pass in C, everything else the Python restatement) against the NumPy
+    environment on an agent episode, and against the reference fixture G3 itself."""
+    rng = np.random.RandomState(9)
+    envs = []
+    for cls in (O.OracleDaisyWorld, O.OracleDaisyWorldC):
+        np.random.seed(21)
+        env = cls(grid_dimension=12, n_agents=3, batch_size=4)
+        obs = env.reset()
+        envs.append((env, obs))
+    np.testing.assert_allclose(envs[0][1], envs[1][1], rtol=1e-12, atol=0)   # un-rounded initial temperatures
+    for t in range(25):
+        a = rng.randint(9, size=(4, 3, 1))
+        ra, rb = envs[0][0].step(a.copy()), envs[1][0].step(a.copy())
+        for x, y in zip(ra[:3], rb[:3]):
+            assert np.array_equal(x, y), t
+        assert np.array_equal(envs[0][0].grid, envs[1][0].grid)
+        # un-rounded caches: pow() against ** 0.25 and another summation order (a few 1e-16 relative)
+        np.testing.assert_allclose(envs[0][0].growth, envs[1][0].growth, rtol=1e-9, atol=1e-15)
+        np.testing.assert_allclose(envs[0][0].temp, envs[1][0].temp, rtol=1e-12)
+    g = golden("G3_agents")
+    env = O.OracleDaisyWorldC(grid_dimension=8, n_agents=4, batch_size=4)
+    env.L = float(g["L0"])
+    env.set_initial_cover(g["light0"], g["dark0"])
+    env.L = float(g["L0"])
+    env.agent_indices = g["agent_indices0"].copy()
+    env.agent_states = g["agent_states0"].copy()
+    for t, a in enumerate(_g3_actions(g)):
+        obs, reward, done, _ = env.step(a)
+        assert np.array_equal(env.agent_indices, g["agent_indices"][t]), t
+        assert np.array_equal(env.agent_states, g["agent_states"][t]), t
+        assert np.array_equal(obs, g["obs"][t]), t
+        assert np.array_equal(reward, g["reward"][t]) and np.array_equal(done, g["done"][t]), t
+        assert env.L == g["L_after"][t]
+    assert np.array_equal(env.grid, g["grid_final"])
+
+
 def test_g10_mlp_policy(golden):
     g = golden("G10_mlp")
     agent, adversary = O.OracleMLP(g["params_agent"]), O.OracleMLP(g["params_adversary"])

@@ -58,6 +58,7 @@ SIGNATURES = {
     "dw_get_params": (C.c_int, [_vp, C.POINTER(DwParams)]),
     "dw_last_error": (C.c_char_p, []),
     "dw_abi_version": (C.c_int, []),
+    "dw_build_id": (C.c_char_p, []),
     "dw_upload_state_f64": (C.c_int, [_vp, _pd, _pd]),
     "dw_upload_state_f32": (C.c_int, [_vp, _pf, _pf, C.c_int]),
     "dw_upload_agents": (C.c_int, [_vp, _pi, _pd]),
@@ -121,9 +122,10 @@ def load(path=None):
     return _libs[path]
 
 
-def check(rc):
+def check(rc, lib=None):
+    """Raise on a non-zero return code, with the message of the library that produced it."""
     if rc != DW_OK:
-        raise DaisyHipError(rc, load().dw_last_error().decode("utf-8", "replace"))
+        raise DaisyHipError(rc, (lib or load()).dw_last_error().decode("utf-8", "replace"))
 
 
 def ptr_d(a):

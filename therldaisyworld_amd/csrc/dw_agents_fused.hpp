@@ -41,7 +41,7 @@ __device__ inline unsigned int fast1_word(const TI* __restrict__ pL, const TI* _
     const float Ed = (at(pD, rr, cl) + at(pD, rr, cr)) + (at(pD, ru, cc) + at(pD, rd, cc));
     const float Cd = (at(pD, ru, cl) + at(pD, ru, cr)) + (at(pD, rd, cl) + at(pD, rd, cr));
     const float li = at(pL, rr, cc), di = at(pD, rr, cc);
-    const GrowthF32 g = growth_t<false, float>(P, li, di, El, Cl, Ed, Cd);
+    const GrowthF32 g = growth_t<kFastSplit, float>(P, li, di, El, Cl, Ed, Cd);
     return (unsigned int)finish_fast(li, g.gql) | ((unsigned int)finish_fast(di, g.gqd) << 16);
 }
 
@@ -54,7 +54,7 @@ __device__ inline unsigned int fast_word_from9(const unsigned int* w, const Phys
     const float Cl = (l[0] + l[2]) + (l[6] + l[8]);
     const float Ed = (d[3] + d[5]) + (d[1] + d[7]);
     const float Cd = (d[0] + d[2]) + (d[6] + d[8]);
-    const GrowthF32 g = growth_t<false, float>(P, l[4], d[4], El, Cl, Ed, Cd);
+    const GrowthF32 g = growth_t<kFastSplit, float>(P, l[4], d[4], El, Cl, Ed, Cd);
     return (unsigned int)finish_fast(l[4], g.gql) | ((unsigned int)finish_fast(d[4], g.gqd) << 16);
 }
 

@@ -592,6 +592,13 @@ extern "C" {
 const char* dw_last_error(void) { return g_err; }
 int dw_abi_version(void) { return DW_ABI_VERSION; }
 
+#ifndef DW_BUILD_ID
+#define DW_BUILD_ID "unknown"
+#endif
+// the marker makes the id findable in the file without loading it (therldaisyworld_amd/build.py)
+static const char kBuildId[] = "DW_BUILD_ID=" DW_BUILD_ID;
+const char* dw_build_id(void) { return kBuildId + 12; }
+
 int dw_default_params(dw_params* p, int32_t batch, int32_t height, int32_t width, int32_t n_agents) {
     NEED(p, DW_EINVAL, "null params");
     std::memset(p, 0, sizeof(*p));
@@ -613,6 +620,9 @@ static int check_params(const dw_params* p) {
     NEED(p->batch >= 1 && p->height >= 3 && p->width >= 3, DW_EINVAL,
          "need batch>=1 and grid >= 3x3 (got B=%d H=%d W=%d)", p->batch, p->height, p->width);
     NEED(p->height <= 65535 && p->width <= 65532, DW_EINVAL, "grid dimension too large");
+    // cell indices inside one world are int32 in the host code and in every kernel
+    NEED((long long)p->height * p->width <= 0x7fffffffLL, DW_EINVAL,
+         "a world of %dx%d cells exceeds the 2^31-1 cells per world the kernels index", p->height, p->width);
     NEED(p->n_agents >= 0, DW_EINVAL, "n_agents < 0");
     NEED(p->precision >= 0 && p->precision <= 2, DW_EINVAL, "bad precision %d", p->precision);
     NEED((double)p->batch * p->height * p->width < 9.0e18, DW_EINVAL, "too many cells");

@@ -98,7 +98,7 @@ __device__ __forceinline__ void cells4(const PhysF32& P, const Row4& upL, const 
         const T Cl = pr(upL.h2) + pr(dnL.h2);
         const T Ed = pr(miD.h2) + (pr(upD.x) + pr(dnD.x));
         const T Cd = pr(upD.h2) + pr(dnD.h2);
-        const GrowthT<T> g = growth_t<EXACT, T>(P, li, di, El, Cl, Ed, Cd);
+        const GrowthT<T> g = growth_t<EXACT || kFastSplit, T>(P, li, di, El, Cl, Ed, Cd);
         T vl, vd;
         if (EXACT) {
             bool tl[N], td[N];

@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void episode_small(EpisodeIO io, int B, int N,
                 const float Cl = (curL[ru + cl] + curL[rd + cl]) + (curL[ru + cr] + curL[rd + cr]);
                 const float Ed = (curD[ru + cc] + curD[rd + cc]) + (curD[rm + cl] + curD[rm + cr]);
                 const float Cd = (curD[ru + cl] + curD[rd + cl]) + (curD[ru + cr] + curD[rd + cr]);
-                const GrowthF32 g = growth_f32<EXACT>(P, li, di, El, Cl, Ed, Cd);
+                const GrowthF32 g = growth_f32<EXACT || kFastSplit>(P, li, di, El, Cl, Ed, Cd);
                 float kl, kd;
                 if (EXACT) {
                     bool tl, td;

@@ -229,6 +229,14 @@ struct GrowthT {
 };
 using GrowthF32 = GrowthT<float>;
 
+// Coefficient chain of the float32-only mode: one rounded coefficient each (0, the default: 3 instructions
+// fewer per cell) or the exact mode's hi/lo split (1).  Measured per-step deviation from the float64
+// reference with both: profiles/r02_fast_tolerance.json (tools/fast_tolerance.py).
+#ifndef DW_FAST_SPLIT
+#define DW_FAST_SPLIT 0
+#endif
+constexpr bool kFastSplit = DW_FAST_SPLIT != 0;
+
 // El/Cl: sums of the 4 edge / 4 corner neighbours of light; Ed/Cd of dark; li/di the centre.
 // SPLIT = true: hi/lo coefficient chains (exact mode: its tie bound relies on the exact hi chain).
 // SPLIT = false: one float32 coefficient each (float32-only mode: 6 instructions fewer per cell).

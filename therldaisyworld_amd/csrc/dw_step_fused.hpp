@@ -391,6 +391,7 @@ __device__ __forceinline__ void fused2_body(const TI* __restrict__ inL, const TI
         };
         unsigned int nmm = 0;
         bool redo = nq > (unsigned)G.qcap;
+        if (nq) wait_row_stores_before_patching();              // wave-uniform; F2 / F3 / the fallback patch stored rows
         if (!redo) {
             // F1 + F2 in one sweep over the queue (the entries differ only in the luminosity of their
             // float64 re-evaluation): a step-1 entry whose float32 value was wrong goes to the mismatch

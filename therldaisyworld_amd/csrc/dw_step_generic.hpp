@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void step_generic(const InT* __restrict__ inL,
             const float Ed = (DW_AT(pd, ru, c) + DW_AT(pd, rd, c)) + (DW_AT(pd, r, cl) + DW_AT(pd, r, cr));
             const float Cd = (DW_AT(pd, ru, cl) + DW_AT(pd, rd, cl)) + (DW_AT(pd, ru, cr) + DW_AT(pd, rd, cr));
 #undef DW_AT
-            const GrowthF32 g = growth_f32<PREC != 1>(P, li, di, El, Cl, Ed, Cd);
+            const GrowthF32 g = growth_f32<PREC != 1 || kFastSplit>(P, li, di, El, Cl, Ed, Cd);
             if (PREC == 1) {
                 kl = finish_fast(li, g.gql);
                 kd = finish_fast(di, g.gqd);

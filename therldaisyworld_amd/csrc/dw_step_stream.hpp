@@ -185,6 +185,18 @@ __device__ __forceinline__ void pack3(const Row4& L, const Row4& D, unsigned int
 
 constexpr int kWaveQueueCap = 256;          // near-tie entries per wave-strip held in LDS (48 B each)
 
+// Ordering of the exact mode's repair stores.  A repaired cell is first written by the strip loop (a 16- or
+// 8-byte non-temporal row store of some lane) and later patched by another lane of the SAME wave with a scalar
+// store to an address inside that row store.  Both are issued in program order by one wave, but nothing in the
+// ISA orders two stores of different lanes and cache policies to overlapping bytes until the first has been
+// acknowledged; on gfx9-family parts stores are counted in vmcnt, so `s_waitcnt vmcnt(0)` after the strip loop
+// waits until every row store of the wave has been written to L2 before the first patch store is issued.
+// Once per strip: free.
+__device__ __forceinline__ void wait_row_stores_before_patching() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // compiler: no store moves across
+    __builtin_amdgcn_s_waitcnt(0x0F70);                        // gfx9 encoding: vmcnt(0), expcnt / lgkmcnt untouched
+}
+
 template <int I>
 __device__ __forceinline__ void queue_tie(bool tie, unsigned int& n, uint4* __restrict__ q, unsigned int cap, int b,
                                           int row, int colq,
@@ -327,6 +339,7 @@ __device__ __forceinline__ void stream_body(const float* __restrict__ inL, const
 
     // ---- exact mode: float64 re-evaluation of this wave's queued near-tie cells ----
     if (EXACT) {
+        if (nq) wait_row_stores_before_patching();              // wave-uniform
         if (nq <= (unsigned)G.qcap) {
             for (unsigned int e = lane; e < nq; e += 64) {
                 const uint4 e0 = q[e * 3], e1 = q[e * 3 + 1], e2 = q[e * 3 + 2];

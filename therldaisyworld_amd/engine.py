@@ -11,7 +11,7 @@ import ctypes as C
 import numpy as np
 
 from . import _ffi
-from ._ffi import DwParams, DwWorldStats, check
+from ._ffi import DwParams, DwWorldStats
 
 VON_NEUMANN_MASK = 0x0BA
 MOORE_MASK = 0x1FF
@@ -32,7 +32,7 @@ def mask_bits(neighborhood: np.ndarray) -> int:
 
 def default_params(batch, height, width, n_agents) -> DwParams:
     p = DwParams()
-    check(_ffi.load().dw_default_params(C.byref(p), batch, height, width, n_agents))
+    _ffi.check(_ffi.load().dw_default_params(C.byref(p), batch, height, width, n_agents))
     return p
 
 
@@ -42,9 +42,12 @@ class Engine:
         self._h = C.c_void_p()
         self.params = DwParams()
         C.memmove(C.byref(self.params), C.byref(params), C.sizeof(DwParams))
-        check(self._lib.dw_create(C.byref(self.params), C.byref(self._h)))
+        self._check(self._lib.dw_create(C.byref(self.params), C.byref(self._h)))
         p = self.params
         self.B, self.H, self.W, self.N = p.batch, p.height, p.width, p.n_agents
+
+    def _check(self, rc):
+        _ffi.check(rc, self._lib)                           # the message of THIS engine's library build
 
     # -- life cycle ---------------------------------------------------------------------------
     def close(self):
@@ -59,7 +62,7 @@ class Engine:
             pass
 
     def set_params(self, params: DwParams):
-        check(self._lib.dw_set_params(self._h, C.byref(params)))
+        self._check(self._lib.dw_set_params(self._h, C.byref(params)))
         C.memmove(C.byref(self.params), C.byref(params), C.sizeof(DwParams))
 
     # -- state --------------------------------------------------------------------------------
@@ -71,35 +74,35 @@ class Engine:
 
     def upload_state(self, light, dark):
         light, dark = self._plane(light, np.float64), self._plane(dark, np.float64)
-        check(self._lib.dw_upload_state_f64(self._h, _ffi.ptr_d(light), _ffi.ptr_d(dark)))
+        self._check(self._lib.dw_upload_state_f64(self._h, _ffi.ptr_d(light), _ffi.ptr_d(dark)))
 
     def upload_state_f32(self, light, dark, quantised=False):
         light, dark = self._plane(light, np.float32), self._plane(dark, np.float32)
-        check(self._lib.dw_upload_state_f32(self._h, _ffi.ptr_f(light), _ffi.ptr_f(dark), int(quantised)))
+        self._check(self._lib.dw_upload_state_f32(self._h, _ffi.ptr_f(light), _ffi.ptr_f(dark), int(quantised)))
 
     def upload_agents(self, indices, states):
         idx = np.ascontiguousarray(indices, dtype=np.int32).reshape(self.B, self.N, 2)
         st = np.ascontiguousarray(states, dtype=np.float64).reshape(self.B, self.N)
-        check(self._lib.dw_upload_agents(self._h, _ffi.ptr_i(idx), _ffi.ptr_d(st)))
+        self._check(self._lib.dw_upload_agents(self._h, _ffi.ptr_i(idx), _ffi.ptr_d(st)))
 
     def download_agents(self):
         idx = np.empty((self.B, self.N, 2), dtype=np.int32)
         st = np.empty((self.B, self.N), dtype=np.float64)
-        check(self._lib.dw_download_agents(self._h, _ffi.ptr_i(idx), _ffi.ptr_d(st)))
+        self._check(self._lib.dw_download_agents(self._h, _ffi.ptr_i(idx), _ffi.ptr_d(st)))
         return idx, st
 
     def init_random(self, seed: int):
-        check(self._lib.dw_init_random(self._h, C.c_uint64(seed & (2 ** 64 - 1))))
+        self._check(self._lib.dw_init_random(self._h, C.c_uint64(seed & (2 ** 64 - 1))))
 
     def download_planes(self, which=_ffi.STATE_CURRENT):
         light = np.empty((self.B, self.H, self.W))
         dark = np.empty((self.B, self.H, self.W))
-        check(self._lib.dw_download_planes(self._h, which, _ffi.ptr_d(light), _ffi.ptr_d(dark)))
+        self._check(self._lib.dw_download_planes(self._h, which, _ffi.ptr_d(light), _ffi.ptr_d(dark)))
         return light, dark
 
     def download_grid(self, L_init=0.75):
         grid = np.empty((self.B, 7, self.H, self.W))
-        check(self._lib.dw_download_grid(self._h, float(L_init), _ffi.ptr_d(grid)))
+        self._check(self._lib.dw_download_grid(self._h, float(L_init), _ffi.ptr_d(grid)))
         return grid
 
     def download_caches(self, L, temps=True, betas=True, growth=True, temp_effective=True):
@@ -108,7 +111,7 @@ class Engine:
         b = np.empty((B, 3, H, W)) if betas else None
         g = np.empty((B, 2, H, W)) if growth else None
         e = np.empty((B, 1, H, W)) if temp_effective else None
-        check(self._lib.dw_download_caches(self._h, float(L), _ffi.ptr_d(t), _ffi.ptr_d(b), _ffi.ptr_d(g),
+        self._check(self._lib.dw_download_caches(self._h, float(L), _ffi.ptr_d(t), _ffi.ptr_d(b), _ffi.ptr_d(g),
                                            _ffi.ptr_d(e)))
         return t, b, g, e
 
@@ -130,10 +133,10 @@ class Engine:
 
     def step(self, L, action=None):
         if action is None:
-            check(self._lib.dw_step(self._h, None, 0, 0, float(L)))
+            self._check(self._lib.dw_step(self._h, None, 0, 0, float(L)))
         else:
             a = self._actions(action)
-            check(self._lib.dw_step(self._h, _ffi.ptr_i(a), a.shape[0], a.shape[1], float(L)))
+            self._check(self._lib.dw_step(self._h, _ffi.ptr_i(a), a.shape[0], a.shape[1], float(L)))
 
     def env_step(self, L, action=None):
         """step + get_obs + reward/done in one call with one synchronisation.  Returns
@@ -146,32 +149,32 @@ class Engine:
         else:
             a = self._actions(action)
             ab, an = a.shape
-        check(self._lib.dw_env_step(self._h, _ffi.ptr_i(a), ab, an, float(L), _ffi.ptr_d(obs), _ffi.ptr_d(reward),
+        self._check(self._lib.dw_env_step(self._h, _ffi.ptr_i(a), ab, an, float(L), _ffi.ptr_d(obs), _ffi.ptr_d(reward),
                                     _ffi.ptr_u8(done)))
         return obs, reward, done.astype(bool)
 
     def step_device_actions(self, L):
-        check(self._lib.dw_step_device_actions(self._h, float(L)))
+        self._check(self._lib.dw_step_device_actions(self._h, float(L)))
 
     def step_n(self, nsteps, L, dL, min_L, max_L, use_device_actions=False):
         Lc = C.c_double(float(L))
-        check(self._lib.dw_step_n(self._h, int(nsteps), C.byref(Lc), float(dL), float(min_L), float(max_L),
+        self._check(self._lib.dw_step_n(self._h, int(nsteps), C.byref(Lc), float(dL), float(min_L), float(max_L),
                                   int(bool(use_device_actions))))
         return Lc.value
 
     def update_agents(self, action):
         a = self._actions(action)
-        check(self._lib.dw_update_agents(self._h, _ffi.ptr_i(a), a.shape[0], a.shape[1]))
+        self._check(self._lib.dw_update_agents(self._h, _ffi.ptr_i(a), a.shape[0], a.shape[1]))
 
     def upload_actions(self, action):
         a = self._actions(action)
         if a.shape != (self.B, self.N):
             raise ValueError(f"device action buffer needs shape {(self.B, self.N)}")
-        check(self._lib.dw_upload_actions(self._h, _ffi.ptr_i(a)))
+        self._check(self._lib.dw_upload_actions(self._h, _ffi.ptr_i(a)))
 
     def download_actions(self):
         a = np.empty((self.B, self.N), dtype=np.int32)
-        check(self._lib.dw_download_actions(self._h, _ffi.ptr_i(a)))
+        self._check(self._lib.dw_download_actions(self._h, _ffi.ptr_i(a)))
         return a
 
     def forward(self, light, dark, L, want_caches=False):
@@ -182,42 +185,42 @@ class Engine:
             t, b, g, e = np.empty((B, 3, H, W)), np.empty((B, 3, H, W)), np.empty((B, 2, H, W)), np.empty((B, 1, H, W))
         else:
             t = b = g = e = None
-        check(self._lib.dw_forward_f64(self._h, _ffi.ptr_d(light), _ffi.ptr_d(dark), float(L), _ffi.ptr_d(grid),
+        self._check(self._lib.dw_forward_f64(self._h, _ffi.ptr_d(light), _ffi.ptr_d(dark), float(L), _ffi.ptr_d(grid),
                                        _ffi.ptr_d(t), _ffi.ptr_d(b), _ffi.ptr_d(g), _ffi.ptr_d(e)))
         return (grid, t, b, g, e) if want_caches else grid
 
     def get_obs(self, L_init=0.75):
         obs = np.zeros((self.B, self.N, 7, 3, 3))
         if self.B * self.N:
-            check(self._lib.dw_get_obs(self._h, float(L_init), _ffi.ptr_d(obs)))
+            self._check(self._lib.dw_get_obs(self._h, float(L_init), _ffi.ptr_d(obs)))
         return obs
 
     def reward_done(self):
         reward = np.zeros((self.B, self.N, 1))
         done = np.zeros((self.B, self.N, 1), dtype=np.uint8)
         if self.B * self.N:
-            check(self._lib.dw_get_reward_done(self._h, _ffi.ptr_d(reward), _ffi.ptr_u8(done)))
+            self._check(self._lib.dw_get_reward_done(self._h, _ffi.ptr_d(reward), _ffi.ptr_u8(done)))
         return reward, done.astype(bool)
 
     def reduce(self):
         out = np.zeros(self.B, dtype=_ffi.STATS_DTYPE)
-        check(self._lib.dw_reduce(self._h, out.ctypes.data_as(C.POINTER(DwWorldStats))))
+        self._check(self._lib.dw_reduce(self._h, out.ctypes.data_as(C.POINTER(DwWorldStats))))
         return out
 
     def policy_greedy(self, argmin=False):
-        check(self._lib.dw_policy_greedy(self._h, _ffi.POLICY_ARGMIN if argmin else _ffi.POLICY_ARGMAX))
+        self._check(self._lib.dw_policy_greedy(self._h, _ffi.POLICY_ARGMIN if argmin else _ffi.POLICY_ARGMAX))
 
     def policy_per_agent(self, agent_mode):
         """agent_mode (N,) of POLICY_ARGMAX / POLICY_ARGMIN / POLICY_TABLE (keep the uploaded action)."""
         m = np.ascontiguousarray(agent_mode, dtype=np.int32)
         if m.shape != (self.N,):
             raise ValueError(f"agent_mode must have shape {(self.N,)}")
-        check(self._lib.dw_policy_per_agent(self._h, _ffi.ptr_i(m)))
+        self._check(self._lib.dw_policy_per_agent(self._h, _ffi.ptr_i(m)))
 
     def policy_mlp(self, params, agent_begin=0, agent_end=None, L_init=0.75):
         w = np.ascontiguousarray(params, dtype=np.float64).ravel()
         end = self.N if agent_end is None else int(agent_end)
-        check(self._lib.dw_policy_mlp(self._h, _ffi.ptr_d(w), int(w.size), int(agent_begin), end, float(L_init)))
+        self._check(self._lib.dw_policy_mlp(self._h, _ffi.ptr_d(w), int(w.size), int(agent_begin), end, float(L_init)))
 
     def policy_mlp_population(self, params, world_member, agent_begin=0, agent_end=None, L_init=0.75):
         """params (P,1808); world_member (B,) int: which parameter set each world's agents use."""
@@ -228,29 +231,29 @@ class Engine:
         if m.shape != (self.B,):
             raise ValueError(f"world_member must have shape {(self.B,)}")
         end = self.N if agent_end is None else int(agent_end)
-        check(self._lib.dw_policy_mlp_population(self._h, _ffi.ptr_d(w), int(w.shape[0]), _ffi.ptr_i(m),
+        self._check(self._lib.dw_policy_mlp_population(self._h, _ffi.ptr_d(w), int(w.shape[0]), _ffi.ptr_i(m),
                                                  int(agent_begin), end, float(L_init)))
 
     def lifespan_reset(self):
-        check(self._lib.dw_lifespan_reset(self._h))
+        self._check(self._lib.dw_lifespan_reset(self._h))
 
     def lifespan_accumulate(self, threshold_k=5):
-        check(self._lib.dw_lifespan_accumulate(self._h, int(threshold_k)))
+        self._check(self._lib.dw_lifespan_accumulate(self._h, int(threshold_k)))
 
     def lifespan_download(self):
         done_at = np.zeros(self.B, dtype=np.int32)
         agents = np.zeros((self.B, self.N, 1), dtype=np.int32)
         alive = C.c_int32(0)
-        check(self._lib.dw_lifespan_download(self._h, _ffi.ptr_i(done_at), _ffi.ptr_i(agents) if self.N else None,
+        self._check(self._lib.dw_lifespan_download(self._h, _ffi.ptr_i(done_at), _ffi.ptr_i(agents) if self.N else None,
                                              C.byref(alive)))
         return done_at, agents, alive.value
 
     def snapshot_save(self):
         """Device-side copy of the current state (planes, agents, reductions)."""
-        check(self._lib.dw_snapshot_save(self._h))
+        self._check(self._lib.dw_snapshot_save(self._h))
 
     def snapshot_restore(self):
-        check(self._lib.dw_snapshot_restore(self._h))
+        self._check(self._lib.dw_snapshot_restore(self._h))
 
     def run_episode(self, L_schedule, policy_mode, use_table=None, table=None, threshold_k=5, world_flags=True):
         """K device-resident steps (one launch for H*W <= 4096, back-to-back launches otherwise).
@@ -268,7 +271,7 @@ class Engine:
             raise ValueError(f"table must have shape {(K, self.B, self.N)}")
         alive = np.zeros((K, self.B), dtype=np.uint8) if world_flags else None
         ok = np.zeros((K, self.B, self.N), dtype=np.uint8)
-        check(self._lib.dw_run_episode(
+        self._check(self._lib.dw_run_episode(
             self._h, K, _ffi.ptr_d(Ls), int(policy_mode), _ffi.ptr_u8(ut),
             None if tb is None else tb.ctypes.data_as(C.POINTER(C.c_int8)), int(threshold_k), _ffi.ptr_u8(alive),
             _ffi.ptr_u8(ok) if self.N else None))
@@ -289,42 +292,42 @@ class Engine:
         split = self.N // 2 if split is None else int(split)
         reward = np.zeros((K, self.B, self.N, 1))
         done = np.zeros((K, self.B, self.N, 1), dtype=np.uint8)
-        check(self._lib.dw_run_episode_mlp(self._h, K, _ffi.ptr_d(Ls), _ffi.ptr_d(w), w.shape[0], _ffi.ptr_i(ma),
+        self._check(self._lib.dw_run_episode_mlp(self._h, K, _ffi.ptr_d(Ls), _ffi.ptr_d(w), w.shape[0], _ffi.ptr_i(ma),
                                            _ffi.ptr_i(mb), split, float(L_init), _ffi.ptr_d(reward), _ffi.ptr_u8(done)))
         return reward, done.astype(bool)
 
     # -- plumbing -----------------------------------------------------------------------------
     def set_stream(self, hip_stream_ptr: int):
-        check(self._lib.dw_set_stream(self._h, C.c_void_p(hip_stream_ptr)))
+        self._check(self._lib.dw_set_stream(self._h, C.c_void_p(hip_stream_ptr)))
 
     def sync(self):
-        check(self._lib.dw_sync(self._h))
+        self._check(self._lib.dw_sync(self._h))
 
     def timer_start(self):
-        check(self._lib.dw_timer_start(self._h))
+        self._check(self._lib.dw_timer_start(self._h))
 
     def timer_stop(self) -> float:
         ms = C.c_float(0)
-        check(self._lib.dw_timer_stop(self._h, C.byref(ms)))
+        self._check(self._lib.dw_timer_stop(self._h, C.byref(ms)))
         return ms.value
 
     def device_planes(self, which=_ffi.STATE_CURRENT):
         lp, dp = C.c_void_p(), C.c_void_p()
-        check(self._lib.dw_device_planes(self._h, which, C.byref(lp), C.byref(dp)))
+        self._check(self._lib.dw_device_planes(self._h, which, C.byref(lp), C.byref(dp)))
         return lp.value, dp.value
 
     def kernel_info(self) -> str:
         buf = C.create_string_buffer(512)
-        check(self._lib.dw_kernel_info(self._h, buf, 512))
+        self._check(self._lib.dw_kernel_info(self._h, buf, 512))
         return buf.value.decode()
 
     def audit_tie_bound(self, L):
         """(max |gq32-gq64| in quanta, max error/bound, flagged cell-values, audited cell-values)."""
         out = np.zeros(4)
-        check(self._lib.dw_audit_tie_bound(self._h, float(L), _ffi.ptr_d(out)))
+        self._check(self._lib.dw_audit_tie_bound(self._h, float(L), _ffi.ptr_d(out)))
         return float(out[0]), float(out[1]), int(out[2]), int(out[3])
 
     def last_fixup_count(self) -> int:
         v = C.c_uint64(0)
-        check(self._lib.dw_last_fixup_count(self._h, C.byref(v)))
+        self._check(self._lib.dw_last_fixup_count(self._h, C.byref(v)))
         return int(v.value)
