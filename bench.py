@@ -1,27 +1,33 @@
 #!/usr/bin/env python3
 """bench.py — cell-updates/s of the fused RLDaisyWorld step on MI355X, with roofline and CPU baseline.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4|c5|c1|target] [--precision fast|exact]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload target|c2|c3|c4|c5|c1] [--precision exact|fast]
 
-A "step" is one pass of the hot path (ref RLDaisyWorld.step, daisy_world_rl.py:475-497) over the
-whole batch of synthetic worlds: update_agents (if the workload has agents) + the fused
-stencil/reaction kernel + per-world reductions.  State is resident in HBM before the timed region
-(device-side Philox initial state).  One process per GPU; worlds are independent, so
-ranks share nothing in the data path (weak scaling: every rank steps its own `worlds` worlds) and
-RCCL is used only for the barrier / max-over-ranks timing and a final gather of per-world statistics.
+A "step" is one pass of the hot path (ref RLDaisyWorld.step, daisy_world_rl.py:475-497) over the whole
+batch of synthetic worlds: update_agents (if the workload has agents) + the fused stencil/reaction
+kernel + per-world reductions.  State is resident in HBM before the timed region (device-side Philox
+initial state).  One process per GPU; worlds are independent, so ranks share nothing in the
+data path (weak scaling: every rank steps its own `worlds` worlds) and RCCL is used only for the barrier /
+max-over-ranks timing and a final gather of per-world statistics.  `--gpus N` without a torchrun
+environment launches the N ranks itself (children only: the parent never touches the GPU).
 
-Arithmetic modes: `fast` (default here) is float32 arithmetic — every cell within one quantum (1e-3) of
-the float64 reference per step, >= 99.5 % identical (tests/test_gpu_parity.py) — and on wide grids
-without agents dw_step_n runs TWO steps per launch (temporal blocking: step-1 rows live only in
-registers) and keeps the states between its launches as binary16 planes (lossless for the quantised
-state), so its algorithmic GB/s can exceed the HBM peak; `exact` (the drop-in class's default) is
-float32 plus a float64 re-evaluation of every near-tie cell and is bit-identical to the float64 reference.
-Both are measured; the one not chosen by --precision is reported under "modes".
+Default workload: the north-star shape, 1024 worlds of 4096x4096 on ONE GPU (128 GiB of binary16 ping-pong
+state; if the allocation fails the world count is halved until it fits and the line says so).  The C2
+workload (BASELINE configs[1], 1024 x 256^2) is measured in the same invocation and reported under
+"workloads".  Headline arithmetic mode: `exact` (float32 + float64 re-evaluation of near-tie cells:
+bit-identical to the float64 reference, the mode whose parity is pinned); `fast` (float32 only) is measured
+too and reported under "modes".
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with extra objects:
-  roofline     algorithmic 16 B per cell-update (float32 light+dark read once, written once) x the
-               cells of one launch / the step kernel's average launch duration measured here with HIP
-               events on the kernel's own stream, against the 8 TB/s HBM3E peak.
+Prints ONE JSON line on rank 0 (contract in the task statement) with these extra objects:
+  roofline     per launch of the dominant kernel (the fused step-pair kernel: one launch = 2 steps):
+               `achieved` = ALGORITHMIC bytes of a launch / its measured duration, where algorithmic bytes
+               follow SURVEY 8(d): 4 x sizeof(plane element) per cell-update in the storage format of that
+               launch (binary16 planes: 8 B) - never the 16 B of float32 storage; `launch_ms` comes from
+               HIP events recorded on the kernel's own stream around the run of fused launches inside the
+               timed region (dw_last_step_n_timing).  `traffic` = HBM bytes per launch from the PMC profile
+               committed under profiles/ (collected separately, as the guide prescribes), `measured_frac` =
+               traffic / launch time / peak; `valu` = VALU instructions per cell-evaluation and SIMD busy
+               fraction from the committed SQ counters; `bound` is what those counters say.
   cpu_baseline the oracle's C restatement (oracle/daisy_oracle.c, "port") timed on this host's cores
                on a bounded sample of the same workload (rank 0, N=1 only).
 """
@@ -31,57 +37,90 @@ import argparse
 import glob
 import json
 import os
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-BYTES_PER_CELL_UPDATE = 16       # 2 x float32 read + 2 x float32 written
 
 WORKLOADS = {
     # name: (worlds per GPU, grid, agents per world, description)
+    "target": (1024, 4096, 0, "north-star target: 1024 worlds of 4096x4096, no agent, ramped luminosity (128 GiB of "
+                              "binary16 ping-pong state on one MI355X)"),
     "c1": (1, 64, 0, "BASELINE configs[0]: 1 world, 64x64, no agent (the reference's CPU-runnable case)"),
     "c2": (1024, 256, 0, "BASELINE configs[1]: 1024 worlds, 256x256, no agent, ramped luminosity"),
     "c3": (256, 1024, 1, "BASELINE configs[2]: 256 worlds, 1024x1024, 1 greedy agent per world"),
     "c5": (8, 8192, 16, "BASELINE configs[4] per-GPU shard: 8 worlds, 8192x8192, 16 mixed-policy agents"),
-    "target": (1024, 4096, 0, "north-star target: 1024 worlds of 4096x4096, no agent (256 GiB of float32 ping-pong "
-                              "state in the 288 GB of one MI355X; --worlds N for a smaller ensemble)"),
     "c4": (1000, 8, 4, "BASELINE configs[3] per-GPU shard at the README's grid: 1000 worlds, 8x8, 4 greedy agents, "
                        "device-resident episode loop (dw_run_episode)"),
 }
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=512,
-                    help="timed steps (default 512: the full luminosity ramp BASELINE configs[1] is defined on)")
-    ap.add_argument("--warmup", type=int, default=64)
-    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--steps", type=int, default=64, help="timed steps")
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--workload", default="target", choices=sorted(WORKLOADS))
     ap.add_argument("--worlds", type=int, default=0, help="override worlds per GPU")
-    ap.add_argument("--precision", default="fast", choices=["exact", "fast", "f64"],
-                    help="arithmetic mode of the headline number (default fast = float32, the tolerance the "
-                         "north star states; the other of exact/fast is measured too and reported under 'modes')")
+    ap.add_argument("--precision", default="exact", choices=["exact", "fast", "f64"],
+                    help="arithmetic mode of the headline number (default exact: bit-identical to the float64 "
+                         "reference; the other of exact/fast is measured too and reported under 'modes')")
     ap.add_argument("--seed", type=int, default=42)
+    ap.add_argument("--preheat-s", type=float, default=2.0,
+                    help="seconds of untimed stepping before the warm-up steps, so that a short timed region does "
+                         "not measure a GPU whose clocks are still rising (reported as preheat_s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--no-modes", action="store_true", help="skip the extra run in the other arithmetic mode")
-    return ap.parse_args()
+    ap.add_argument("--no-workloads", action="store_true", help="skip the extra C2 measurement")
+    ap.add_argument("--selftest-spawn", action="store_true",
+                    help="CPU rehearsal of the N > 1 plumbing (rank launch, rendezvous, barrier, max-over-ranks, "
+                         "gather, rank-0 relay) without touching a GPU: prints the JSON skeleton")
+    return ap.parse_args(argv)
 
 
-def cpu_baseline(grid: int, params_obj, budget_s: float = 15.0):
+# ------------------------------------------------------------------------------------------------
+# N > 1 without torchrun: launch the ranks ourselves
+# ------------------------------------------------------------------------------------------------
+def spawn_ranks(args, argv):
+    """Parent of a self-launched multi-rank run: start `--gpus N` fresh child processes of this script, one per
+    GPU, with the torchrun environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT) set, wait,
+    relay rank 0's JSON line.  The parent imports neither torch nor the HIP library: a process that has
+    initialised the GPU never replaces itself or forks GPU work."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        raise SystemExit(f"bench.py: ranks failed (rank, exit code): {bad}")
+    return 0
+
+
+def cpu_baseline(grid: int, budget_s: float = 15.0):
     """Time the oracle's C restatement on this host: all cores (OpenMP over worlds) on a
     bounded sample of the workload's grid, one thread on one world of it, and BASELINE configs[0] (C1:
     1 world, 64x64, 500 steps) exactly, single thread.  Three repeats each, median."""
     import statistics
+    import numpy as np
     from oracle import c_oracle
     c_oracle.build()
-    cores = max(1, min(c_oracle.max_threads(), len(os.sched_getaffinity(0))))
+    cores = max(1, min(c_oracle.max_threads(), c_oracle.usable_cpus()))   # affinity mask capped by the cgroup quota
     g = min(grid, 256)                               # bounded sample of the workload's grid
     worlds = 2 * cores
     rng = np.random.RandomState(0)
@@ -123,32 +162,59 @@ def cpu_baseline(grid: int, params_obj, budget_s: float = 15.0):
     }
 
 
-def load_traffic(workload: str, precision: str, steps_per_launch: int = 0):
-    """HBM bytes per launch of the dominant kernel from the PMC profile of the same command, if one has
-    been committed under profiles/ (collected per the guide: separate --pmc passes, FETCH_SIZE x2 on
-    gfx950).  `steps_per_launch` (when given) must match the profile's."""
+def load_profile(kind: str, workload: str, precision: str):
+    """Newest committed PMC summary for (workload, precision): kind 'traffic' -> profiles/traffic_*.json (HBM bytes
+    per fused launch: separate --pmc passes, FETCH_SIZE x2 on gfx950), kind 'valu' -> profiles/*_valu_pmc.json
+    (SQ counters of the fused kernel).  Returns (dict, file name) or (None, None)."""
+    pat = "traffic_*.json" if kind == "traffic" else "*_valu_pmc.json"
     best = None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_*.json"))):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", pat))):
         try:
             d = json.load(open(path))
         except Exception:
             continue
-        if d.get("workload") == workload and d.get("precision") == precision:
-            if steps_per_launch and d.get("steps_per_launch", 1) != steps_per_launch:
-                part = d.get("single" if steps_per_launch == 1 else "fused")
-                if not part:
-                    continue
-                d = dict(d, hbm_bytes_per_launch=part["hbm_bytes_per_launch"])
-            best = d
-    return None if best is None else best.get("hbm_bytes_per_launch")
+        if kind == "traffic":
+            if d.get("workload") == workload and d.get("precision") == precision and d.get("plane_elem_bytes", 4) == 2:
+                best = (d.get("fused") or d, os.path.basename(path))
+        else:
+            if str(d.get("workload", "")).split()[0] == workload and d.get("plane_elem_bytes", 4) == 2 and precision in d:
+                best = (d[precision], os.path.basename(path))
+    return best if best else (None, None)
+
+
+def selftest_spawn(args):
+    """The N > 1 plumbing on CPU (gloo): what tests/test_bench_spawn.py runs."""
+    import numpy as np
+    from therldaisyworld_amd import ensemble
+    rank, _, world = ensemble.rank_info()
+    dist = ensemble.init_process_group("gloo") if world > 1 else None
+    B = args.worlds or 3
+    local = np.arange(B, dtype=np.int64) + rank * B
+    if dist is not None:
+        dist.barrier()
+    elapsed = ensemble.max_over_ranks(0.001 * (rank + 1))
+    allw = ensemble.gather_per_world(local) if dist is not None else local
+    if rank == 0:
+        print(json.dumps({"selftest": "spawn", "n_gpus": world, "total_worlds": int(allw.shape[0]),
+                          "worlds": [int(x) for x in allw], "max_elapsed": elapsed}))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def main():
-    args = parse()
+    argv = sys.argv[1:]
+    args = parse(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args, argv)
+    if args.selftest_spawn:
+        return selftest_spawn(args)
+
+    import numpy as np
     from therldaisyworld_amd import ensemble
     rank, local_rank, world = ensemble.rank_info()
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     n_gpus = world
 
     import torch
@@ -162,60 +228,64 @@ def main():
     import therldaisyworld_amd as amd
     from therldaisyworld_amd import _ffi
 
-    B, G, N, desc = WORKLOADS[args.workload]
-    if args.worlds:
-        B = args.worlds
     min_L, max_L, dL = 0.75, 1.5, 0.75 / 512
-    cells = B * G * G
 
-    def measure(precision, steps, warmup):
-        """One timed run of `steps` steps in the given arithmetic mode; returns the numbers of the JSON."""
-        p = amd.default_params(B, G, G, N)
-        p.device = local_rank
-        p.precision = _ffi.PRECISION[precision]
-        p.world_offset = rank * B                       # global world ids: the ensemble is one sweep
-        eng = amd.Engine(p)
-        eng.init_random(args.seed)
-        # per-agent policy for the agent workloads: greedy (c3) or greedy/antigreedy/random/half-random by
-        # agent index (c5).  Random actions are drawn on the host and uploaded.
+    def make_engine(B, G, N, precision):
+        """Engine for B worlds; the world count is halved while the device cannot hold the state."""
+        while True:
+            p = amd.default_params(B, G, G, N)
+            p.device = local_rank
+            p.precision = _ffi.PRECISION[precision]
+            p.world_offset = rank * B                       # global world ids: the ensemble is one sweep
+            eng = None
+            try:
+                eng = amd.Engine(p)
+                eng.init_random(args.seed)
+                return eng, B
+            except amd.DaisyHipError as e:
+                if eng is not None:
+                    eng.close()
+                if e.code != _ffi.DW_ENOMEM or B == 1:
+                    raise
+                B //= 2
+
+    def measure(workload, precision, steps, warmup, preheat_s, worlds=0):
+        """One timed run of `steps` steps of `workload` in the given arithmetic mode."""
+        B, G, N, desc = WORKLOADS[workload]
+        if worlds:
+            B = worlds
+        eng, B = make_engine(B, G, N, precision)
+        if dist is not None:                                # every rank must step the same number of worlds
+            B_all = int(ensemble.max_over_ranks(-B)) * -1
+            if B_all != B:
+                eng.close()
+                eng, B = make_engine(B_all, G, N, precision)
+        cells = B * G * G
         rng = np.random.RandomState(args.seed + rank)
 
-        def run(nsteps, L):
+        def run(nsteps, L, ramp=dL):
             if N == 0:
-                return eng.step_n(nsteps, L, dL, min_L, max_L)
-            if args.workload == "c4":                       # small worlds: whole chunks of steps in one launch
-                if L == min_L:                              # first step from the un-quantised state
-                    eng.policy_greedy(argmin=False)
-                    eng.step_device_actions(L)
-                    L = min(max(L + dL, min_L), max_L)
-                    nsteps -= 1
-                while nsteps > 0:
-                    k = min(nsteps, 64)
-                    Ls = []
-                    for _ in range(k):
-                        Ls.append(L)
-                        L = min(max(L + dL, min_L), max_L)
-                    eng.run_episode(Ls, _ffi.POLICY_ARGMAX)
-                    nsteps -= k
-                return L
-            # agent workloads on wide grids (c3, c5): the episode loop stays on the device in chunks
-            # (dw_run_episode without per-step world flags: step pairs in one fused launch, the agents'
-            # in-between step patched in).  c3: every agent greedy.  c5: agents 0-3 greedy, 4-7 antigreedy,
-            # 8-11 random, 12-15 half-random (one coin per step for the batch, as Greedy does); random
-            # actions are drawn on the host into the int8 table, -1 / -2 stand for the greedy / anti-greedy
-            # choice evaluated on the device; nothing is downloaded but the (K,B,N) agent flags.
-            if L == min_L:                                  # first step from the un-quantised state
+                return eng.step_n(nsteps, L, ramp, min_L, max_L)
+            first = not getattr(run, "started", False)
+            run.started = True
+            if first:                                       # first step from the un-quantised state
                 eng.policy_greedy(argmin=False)
                 eng.step_device_actions(L)
-                L = min(max(L + dL, min_L), max_L)
+                L = min(max(L + ramp, min_L), max_L)
                 nsteps -= 1
+            # agent workloads: the episode loop stays on the device in chunks (dw_run_episode: one launch per
+            # chunk for the 8x8 worlds of c4; step pairs in one fused launch with the agents' in-between step
+            # patched in on the wide grids of c3 / c5).  c3 / c4: every agent greedy.  c5: agents 0-3 greedy,
+            # 4-7 antigreedy, 8-11 random, 12-15 half-random (one coin per step for the batch, as Greedy does);
+            # random actions are drawn on the host into the int8 table, -1 / -2 stand for the greedy /
+            # anti-greedy choice evaluated on the device; nothing is downloaded but the (K,B,N) agent flags.
             while nsteps > 0:
                 k = min(nsteps, 64)
                 Ls = []
                 for _ in range(k):
                     Ls.append(L)
-                    L = min(max(L + dL, min_L), max_L)
-                if args.workload == "c5":
+                    L = min(max(L + ramp, min_L), max_L)
+                if workload == "c5":
                     table = np.empty((k, B, 16), dtype=np.int8)
                     table[:, :, 0:4] = -1
                     table[:, :, 4:8] = -2
@@ -223,12 +293,25 @@ def main():
                     coin = rng.rand(k) > 0.5
                     table[:, :, 12:16] = np.where(coin[:, None, None], -1, rng.randint(9, size=(k, B, 4)))
                     eng.run_episode(Ls, _ffi.POLICY_TABLE, None, table, world_flags=False)
+                elif workload == "c4":
+                    eng.run_episode(Ls, _ffi.POLICY_ARGMAX)
                 else:
                     eng.run_episode(Ls, _ffi.POLICY_ARGMAX, world_flags=False)
                 nsteps -= k
             return L
 
-        L = run(warmup, min_L)
+        # pre-heat at constant luminosity (develops the daisies, does not advance the ramp), then warm-up
+        L = min_L
+        t_pre = time.perf_counter()
+        pre_steps = 0
+        chunk = max(2, min(64, warmup or 8))
+        while time.perf_counter() - t_pre < preheat_s:
+            L = run(chunk, L, 0.0)
+            eng.sync()
+            pre_steps += chunk
+        preheat = time.perf_counter() - t_pre
+        if warmup:
+            L = run(warmup, L)
         eng.sync()
         torch.cuda.synchronize()
         if dist is not None:
@@ -241,72 +324,88 @@ def main():
         if dist is not None:
             dist.barrier()
         elapsed = ensemble.max_over_ranks(time.perf_counter() - t0)
-        ev_ms = ensemble.max_over_ranks(ev_ms)
-        kernel_ms = ev_ms / steps
-        achieved = BYTES_PER_CELL_UPDATE * cells / (kernel_ms * 1e-3) / 1e9
+        fused_ms, fused_n, elem_bytes = eng.last_step_n_timing() if N == 0 else (0.0, 0, 2)
         stats = eng.reduce()
         info = eng.kernel_info()
-        # dw_step_n runs wide agent-free grids as fused step PAIRS: the dominant kernel's launch = 2 steps
-        # (agent workloads c3 / c5 too: dw_run_episode pairs the steps and patches the agents' step in)
-        paired = N == 0 or (args.workload in ("c3", "c5") and not os.environ.get("DW_NO_AGENT_FUSE"))
-        spl = 2 if (paired and "fuses step pairs" in info and not os.environ.get("DW_NO_FUSE")) else 1
-        res = {"value": cells * steps * n_gpus / elapsed, "ms_per_step": elapsed / steps * 1e3,
-               "kernel_ms": kernel_ms, "achieved": achieved, "frac": achieved / HBM_PEAK_GBS,
-               "fixups": eng.last_fixup_count(), "kernel": info, "stats": stats, "steps_per_launch": spl}
+        res = {"workload": workload, "desc": desc, "precision": precision, "B": B, "G": G, "N": N, "cells": cells,
+               "value": cells * steps * n_gpus / elapsed, "ms_per_step": elapsed / steps * 1e3,
+               "event_ms_per_step": ev_ms / steps, "fused_ms": fused_ms, "fused_launches": fused_n,
+               "plane_elem_bytes": elem_bytes, "fixups": eng.last_fixup_count(), "kernel": info, "stats": stats,
+               "preheat_s": preheat, "preheat_steps": pre_steps}
         eng.close()
         return res
 
-    m = measure(args.precision, args.steps, args.warmup)
-    value, kernel_ms, achieved, fixups, info, stats = (m["value"], m["kernel_ms"], m["achieved"], m["fixups"],
-                                                       m["kernel"], m["stats"])
-    elapsed_ms_per_step = m["ms_per_step"]
-    all_stats = ensemble.gather_per_world(stats) if dist is not None else stats   # end-of-run gather (RCCL)
+    def roofline(m):
+        """SURVEY 8(d) accounting for the dominant kernel of run `m` (see the module docstring)."""
+        bpc = 4 * m["plane_elem_bytes"]                 # 2 planes read + 2 written, in the launch's storage format
+        if m["fused_launches"] > 0:
+            spl, launch_ms, timed = 2, m["fused_ms"] / m["fused_launches"], m["fused_launches"]
+            src = "HIP events around the fused launches of the timed dw_step_n call (dw_last_step_n_timing)"
+        else:                                           # single-step launches only (agent workloads, tiny runs)
+            spl, launch_ms, timed = 1, m["event_ms_per_step"], 0
+            src = "HIP events over the whole timed region / steps (includes the agent and policy kernels)"
+        alg = bpc * m["cells"] * spl
+        achieved = alg / (launch_ms * 1e-3) / 1e9
+        tr, tr_file = load_profile("traffic", m["workload"], m["precision"])
+        va, va_file = load_profile("valu", m["workload"], m["precision"])
+        traffic = tr.get("hbm_bytes_per_launch") if tr and spl == 2 else None
+        measured = traffic / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if traffic else None
+        valu = None
+        if va and spl == 2:
+            valu = {"instr_per_cell_eval": va["derived"]["valu_instr_per_cell_eval"],
+                    "busy_frac": va["derived"]["valu_busy_fraction"], "source": f"profiles/{va_file}"}
+        bound = "valu" if (valu and valu["busy_frac"] >= 0.7 and (measured is None or measured < 0.6)) else "hbm"
+        return {"bound": bound, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "measured_frac": measured,
+                "traffic_source": f"profiles/{tr_file} (PMC passes of the same command, collected separately)" if traffic else None,
+                "valu": valu, "bytes_per_cell_update": bpc, "plane_elem_bytes": m["plane_elem_bytes"],
+                "steps_per_launch": spl, "cell_updates_per_launch": m["cells"] * spl,
+                "algorithmic_bytes_per_launch": alg, "launch_ms": launch_ms, "launches_timed": timed,
+                "launch_ms_source": src, "f64_fixups_last_step": m["fixups"]}
 
+    def brief(m):
+        r = roofline(m)
+        return {"value": m["value"], "ms_per_step": m["ms_per_step"], "worlds_per_gpu": m["B"], "grid": [m["G"], m["G"]],
+                "kernel": m["kernel"], "roofline": {k: r[k] for k in ("bound", "achieved", "frac", "traffic", "measured_frac",
+                                                                     "bytes_per_cell_update", "launch_ms", "launches_timed",
+                                                                     "steps_per_launch")}}
+
+    m = measure(args.workload, args.precision, args.steps, args.warmup, args.preheat_s, args.worlds)
+    all_stats = ensemble.gather_per_world(m["stats"]) if dist is not None else m["stats"]   # end-of-run gather (RCCL)
+    B, G, N = m["B"], m["G"], m["N"]
     out = {
         "metric": "cell-updates/sec (grid x batch), fused stencil+growth step",
-        "value": value,
+        "value": m["value"],
         "unit": "cell-updates/s",
         "n_gpus": n_gpus,
         "steps": args.steps,
         "warmup": args.warmup,
-        "ms_per_step": elapsed_ms_per_step,
+        "ms_per_step": m["ms_per_step"],
         "higher_is_better": True,
         "scaling": "weak",
-        "vs_baseline": None,
-        "dtype": {"exact": "f32 (+ f64 re-evaluation of near-tie cells: bit-identical to f64)", "fast": "f32",
-                  "f64": "f64"}[args.precision],
+        "vs_baseline": None,                             # BASELINE.md publishes no throughput for this path
+        "dtype": {"exact": "f32", "fast": "f32", "f64": "f64"}[args.precision],
         "data": "synthetic (device Philox initial state with the distribution of initialize_grid; ramped luminosity)",
-        "config": {"workload": f"{args.workload}: {desc}", "worlds_per_gpu": B, "grid": [G, G], "agents_per_world": N,
-                   "precision": args.precision, "kernel": info, "total_worlds": int(all_stats.shape[0]),
+        "config": {"workload": f"{args.workload}: {m['desc']}", "worlds_per_gpu": B, "grid": [G, G], "agents_per_world": N,
+                   "precision": args.precision + (" (float32 + float64 re-evaluation of near-tie cells: bit-identical to the "
+                                                  "float64 reference)" if args.precision == "exact" else ""),
+                   "plane_format": "binary16 per-mille (lossless for the quantised state)", "kernel": m["kernel"],
+                   "total_worlds": int(all_stats.shape[0]),
                    "parallelism": f"ensemble shard x{n_gpus} (no data-path collective)"},
-        # per launch of the dominant kernel: algorithmic bytes = 16 B x cell-updates of one launch; achieved =
-        # that / the launch duration (HIP events on the kernel's stream / launches); traffic = PMC HBM bytes
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": load_traffic(args.workload, args.precision, m["steps_per_launch"]),
-                     "bytes_per_cell_update": BYTES_PER_CELL_UPDATE, "steps_per_launch": m["steps_per_launch"],
-                     "cell_updates_per_launch": cells * m["steps_per_launch"],
-                     "algorithmic_bytes_per_launch": BYTES_PER_CELL_UPDATE * cells * m["steps_per_launch"],
-                     "launch_ms": kernel_ms * m["steps_per_launch"], "kernel_ms_per_step": kernel_ms,
-                     "f64_fixups_last_step": fixups,
-                     "note": ("two steps share one HBM round trip (temporal blocking in registers) and the states "
-                              "between the launches of a run are binary16 planes (lossless: integers <= 1000): measured "
-                              "traffic is about a quarter of the algorithmic bytes, so frac may exceed 1; the fused "
-                              "kernels are VALU-issue-bound (83-85 % busy, profiles/r01k_valu_pmc.json)")
-                     if m["steps_per_launch"] == 2 else "single-step kernel: HBM-bound"},
+        "roofline": roofline(m),
+        "preheat_s": round(m["preheat_s"], 3),
     }
-    if not args.no_modes:
-        # the other arithmetic mode on the same workload, for the record (shorter run).  In "fast" mode
-        # dw_step_n fuses pairs of steps into one launch on wide grids without agents (temporal blocking),
-        # so its algorithmic GB/s may exceed the HBM peak; measured HBM bytes are in profiles/.
+    if WORKLOADS[args.workload][0] != B and not args.worlds:
+        out["config"]["note"] = f"{WORKLOADS[args.workload][0]} worlds did not fit this device: measured {B}"
+    if not args.no_modes and args.precision in ("exact", "fast"):
         other = "fast" if args.precision == "exact" else "exact"
-        o = measure(other, max(10, args.steps // 2), max(4, args.warmup // 2))
-        out["modes"] = {other: {"value": o["value"], "ms_per_step": o["ms_per_step"], "kernel_ms": o["kernel_ms"],
-                                "achieved_GBps": o["achieved"], "frac": o["frac"], "kernel": o["kernel"],
-                                "steps_per_launch": o["steps_per_launch"],
-                                "traffic": load_traffic(args.workload, other, o["steps_per_launch"])}}
+        out["modes"] = {other: brief(measure(args.workload, other, args.steps, args.warmup, min(args.preheat_s, 1.0), B))}
+    if not args.no_workloads and args.workload == "target":
+        # BASELINE configs[1] in the same invocation: the whole luminosity ramp (512 steps after 64 of warm-up)
+        out["workloads"] = {"c2": {p: brief(measure("c2", p, 512, 64, 0.5)) for p in ("exact", "fast")}}
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(G, None)
+        out["cpu_baseline"] = cpu_baseline(G)
+        out["vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:
@@ -314,7 +413,8 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -22,10 +22,25 @@
  *
  * Layout
  *   grids are row-major [world][row][col]; "row" is the reference's axis -2 (which its code calls
- *   x) and "col" its axis -1 (y).  Device state is two planar float32 arrays per buffer (light,
- *   dark) holding the cover in PER-MILLE units (1000 * cover; exactly the integers 0..1000 once a
- *   step has run, because the reference quantises to 3 decimals, daisy_world_rl.py:452), kept
- *   ping-pong so that the pre-step state stays available for observations / materialisation.
+ *   x) and "col" its axis -1 (y).  Device state is two planar BINARY16 arrays per buffer (light,
+ *   dark) holding the cover in PER-MILLE units (1000 * cover: exactly the integers 0..1000 once a
+ *   step has run, because the reference quantises to 3 decimals, daisy_world_rl.py:452 - and binary16
+ *   holds every integer up to 2048 exactly, so the format is lossless: 2 bytes per value, 8 bytes of
+ *   HBM traffic per cell-update), kept ping-pong so that the pre-step state stays available for
+ *   observations / materialisation.  An UN-quantised state (the reference's initial grid is not
+ *   rounded, :285-324) stays in its upload format - float64, or float32 per-mille - until the first
+ *   step has consumed it.
+ *
+ * Numerics of the default mode (DW_PRECISION_EXACT): the light / dark planes after any step, and
+ * everything derived from quantised values (observations, rewards, done flags, lifespans, the rounded
+ * temperature channels), are bit-identical to the reference's float64 NumPy path.  Two caveats, stated
+ * here so that "bit-exact" is not read as a proof: (i) the reference convolves by FFT, this library by
+ * the mathematically identical 9-tap stencil, and the float64 repair path forms T_x^4 directly instead
+ * of through the chain of fourth roots - both differ from the reference by a few 1e-16 relative BEFORE
+ * rounding, the size of the reference's own FFT noise; a cell whose float64 pre-rounding value lies
+ * that close to a rounding tie could round differently (never observed: 1.4e10 cell-updates soaked
+ * against the oracle, 0 mismatches); (ii) un-quantised outputs - reset() observations, env.grid after
+ * reset(), the temp / beta / growth caches - agree with the reference to ~1e-13 relative, not bit for bit.
  */
 #ifndef DAISYWORLD_HIP_H
 #define DAISYWORLD_HIP_H
@@ -37,7 +52,7 @@
 extern "C" {
 #endif
 
-#define DW_ABI_VERSION 1
+#define DW_ABI_VERSION 2
 
 /* ---- error codes ---------------------------------------------------------------------------- */
 enum {
@@ -56,7 +71,10 @@ enum {
      * evaluation of the reference formulas (the default). */
     DW_PRECISION_EXACT = 0,
     /* float32 arithmetic only: every cell within one quantum (1e-3) of the float64 result and
-     * >= 99.5 % of cells identical after one step from the same state. */
+     * >= 99.98 % of the cell values identical after one step from the same state (measured >= 99.994 % on
+     * developed states over the whole luminosity ramp, profiles/r02_fast_tolerance.json); ensemble means
+     * of a trajectory within 3e-4.  A single small world's trajectory diverges cell-wise (one flipped tie
+     * is amplified by the dynamics): that is what the exact mode is for. */
     DW_PRECISION_FAST = 1,
     /* float64 arithmetic for every cell (slow; the in-library reference the other two are tested
      * against, and the path used for the first step from an un-quantised initial state). */
@@ -135,7 +153,9 @@ const char* dw_build_id(void);
  * evaluated in float64 from these exact values.  Resets the retained "previous" state. */
 int dw_upload_state_f64(dw_handle* h, const double* light, const double* dark);
 
-/* Same from float32 natural-unit planes.  quantised != 0 asserts every value is k/1000. */
+/* Same from float32 natural-unit planes.  quantised != 0 asserts every value is k/1000 (it is rounded to the
+ * per-mille integer and goes straight into the binary16 planes); 0: the state is un-quantised, kept as float32
+ * per-mille until the first step. */
 int dw_upload_state_f32(dw_handle* h, const float* light, const float* dark, int quantised);
 
 /* Agent positions [B][N][2] (row, col) and energy stores [B][N] (ref initialize_agents :173-179). */
@@ -193,11 +213,15 @@ int dw_download_actions(dw_handle* h, int32_t* action /* [B][N] */);
  * update_agents call at all (ref `action is None` with n_agents == 0), 1 = actions are taken from
  * the device action buffer every step (constant unless a policy refreshes it).
  * The result equals `nsteps` calls of dw_step bit for bit; how the steps are issued is the library's business
- * (on wide grids two steps share one launch, and the states between the launches of one call live as binary16
- * planes - lossless for the quantised state; everything any other entry point reads is float32 again when the
- * call returns). */
+ * (on wide grids two steps share one launch: step-1 values live only in registers). */
 int dw_step_n(dw_handle* h, int32_t nsteps, double* L_io, double dL, double min_L, double max_L,
               int use_device_actions);
+
+/* Measurement aid (bench.py): duration of the run of fused step-pair launches issued by the LAST
+ * dw_step_n call, from HIP events recorded on the handle's stream immediately before the first and after the
+ * last of them (synchronises).  fused_launches = 0 (and fused_ms = 0) if that call issued none.
+ * plane_elem_bytes = sizeof of the plane element those launches read and write (2: binary16). */
+int dw_last_step_n_timing(dw_handle* h, float* fused_ms, int32_t* fused_launches, int32_t* plane_elem_bytes);
 
 /* update_agents alone (ref :181-244) and forward alone on caller data (ref :434-461).  With
  * collision_mode = 1 dw_update_agents stops before the final clip: the reference's collision pass
@@ -298,7 +322,7 @@ int dw_lifespan_download(dw_handle* h, int32_t* done_at /* [B] */, int32_t* agen
  * world_alive may be NULL: without per-step world reductions wide grids (and big ensembles of narrow
  * ones) run step PAIRS as one fused launch, with the agents' step in between recomputed around the
  * agents and patched into the result (csrc/dw_agents_fused.hpp) - same results, bit for bit.
- * Needs a quantised current state in exact mode (take the first step of an episode with dw_step).
+ * Needs a quantised current state (take the first step of an episode with dw_step).
  * Afterwards the handle is exactly as after K calls of dw_step (previous state retained). */
 enum { DW_POLICY_ZEROS = 2, DW_POLICY_TABLE = 3 };
 int dw_run_episode(dw_handle* h, int32_t nsteps, const double* L_schedule, int policy_mode,
@@ -315,7 +339,8 @@ int dw_sync(dw_handle* h);
 int dw_timer_start(dw_handle* h);
 int dw_timer_stop(dw_handle* h, float* elapsed_ms);
 
-/* Raw device pointers of the current planes (per-mille float32, [B][H][W]) for zero-copy interop. */
+/* Raw device pointers of the current / previous planes (per-mille binary16, [B][H][W]) for zero-copy interop;
+ * DW_ESTATE while the current state is an un-quantised upload (no binary16 planes before the first step). */
 int dw_device_planes(dw_handle* h, int which, void** light, void** dark);
 
 /* Name and geometry of the step kernel the handle dispatches for its shape, for bench/profiles:

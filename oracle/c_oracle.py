@@ -46,6 +46,26 @@ def build(force: bool = False) -> str:
 _lib = None
 
 
+def usable_cpus() -> int:
+    """CPUs this process may actually use: the affinity mask, capped by the cgroup CPU quota (a GPU box hands a
+    job a share of its host cores - 128 visible, ~16 usable: OpenMP teams sized by the visible count thrash)."""
+    n = len(os.sched_getaffinity(0))
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: (t.split()[0], t.split()[1])),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", None)):
+        try:
+            txt = open(path).read().strip()
+            if parse:
+                quota, period = parse(txt)
+            else:
+                quota, period = txt, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().strip()
+            if quota not in ("max", "-1") and float(quota) > 0:
+                n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -59,6 +79,7 @@ def lib():
         _lib.oracle_step_n.restype = C.c_int
         _lib.oracle_set_threads.argtypes = [C.c_int]
         assert _lib.oracle_sizeof_params() == C.sizeof(OracleParams)
+        _lib.oracle_set_threads(min(int(_lib.oracle_max_threads()), usable_cpus()))
     return _lib
 
 

@@ -139,7 +139,7 @@ static void forward_world(const oracle_params *P, double L, int H, int W, const 
 /* fewer worlds than threads and worlds big enough to share out by rows */
 static int few_big_worlds(int B, size_t n) {
 #ifdef _OPENMP
-    return B < omp_get_max_threads() && n >= (size_t)1 << 16;
+    return B < omp_get_max_threads() && n >= (size_t)1 << 19;      /* >= 512k cells: a team per loop pays off */
 #else
     (void)B; (void)n;
     return 0;

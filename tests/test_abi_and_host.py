@@ -41,7 +41,7 @@ def test_struct_layouts_match_header(built):
     p = _ffi.DwParams()
     assert _ffi.load().dw_default_params(C.byref(p), 7, 8, 12, 3) == 0
     assert (p.batch, p.height, p.width, p.n_agents) == (7, 8, 12, 3)
-    assert p.abi_version == 1 and p.obs_mask == 0x0BA and p.precision == 0
+    assert p.abi_version == _ffi.DW_ABI_VERSION and p.obs_mask == 0x0BA and p.precision == 0
     assert p.q == 0.2 * 1000.0 / 5.67e-8 and p.q2 == p.q / 8.0
     assert (p.albedo_bare, p.albedo_light, p.albedo_dark, p.temp_optimal) == (0.5, 0.75, 0.25, 295.5)
     assert (p.agent_gamma, p.light_proportion, p.initial_al) == (0.05, 0.33, 0.2)

@@ -4,8 +4,9 @@ against the CPU oracle and the golden vectors generated from the reference.
 Bars:
   * DW_PRECISION_F64 and DW_PRECISION_EXACT: light/dark planes BIT-EXACT against the float64 oracle
     (integers k = 1000*cover compared), single steps and whole trajectories;
-  * DW_PRECISION_FAST: every cell within one quantum (1e-3) and >= 99.5 % of cells identical after
-    one step from the same state;
+  * DW_PRECISION_FAST: every cell within one quantum (1e-3) and >= 99.98 % of the cell values identical after
+    one step from the same state (measured: >= 99.991 % on synthetic random states, >= 99.994 % on developed
+    states over the whole luminosity ramp; profiles/r02_fast_tolerance*.json);
   * agents / observations / rewards: exact equality with the reference fixtures (float64).
 """
 import numpy as np
@@ -121,10 +122,13 @@ def test_single_step_vs_oracle(amd, B, H, W, precision, L):
     gl, gd = eng.download_planes()
     kl, kd, rl, rd = _k(gl), _k(gd), _k(ref[:, 1]), _k(ref[:, 2])
     if precision == "fast":
+        # synthetic random states: measured worst over these shapes x luminosities 0.0089 % of the cell values
+        # differing, all by one quantum (profiles/r02_fast_tolerance_cases.json); asserted at twice that (and one
+        # flip always allowed, for the tiny grids)
         dl, dd = np.abs(kl - rl), np.abs(kd - rd)
         assert dl.max() <= 1 and dd.max() <= 1, "fast mode: more than one quantum off"
-        frac_equal = 1.0 - (np.count_nonzero(dl) + np.count_nonzero(dd)) / (2.0 * dl.size)
-        assert frac_equal >= 0.995, f"fast mode: only {frac_equal:.5f} of cells identical"
+        n_diff = np.count_nonzero(dl) + np.count_nonzero(dd)
+        assert n_diff <= max(1, int(np.ceil(1.8e-4 * 2 * dl.size))), f"fast mode: {n_diff} of {2 * dl.size} values differ"
     else:
         assert np.array_equal(kl, rl) and np.array_equal(kd, rd), f"{precision}: not bit-exact"
     # fused per-world reductions
@@ -231,10 +235,12 @@ def test_c1_trajectory_bit_exact_g2(amd, golden, precision):
 
 
 def test_c1_trajectory_fast_mode_statistics(amd, golden):
-    """float32-only arithmetic: the population curves of the single 64x64 world of C1 stay within
-    5e-3 absolute of the reference at every one of the 500 steps (measured worst 2.6e-3; cell-wise
-    long-horizon equality is not claimed for this mode: the quantiser amplifies tie flips, which is
-    why the default mode is the exact one)."""
+    """float32-only arithmetic, SINGLE world: the population curves of the 64x64 world of C1 stay within
+    5e-3 absolute of the reference at every one of the 500 steps (measured worst 2.6e-3 = the assert / 2).
+    SURVEY 8(c) hoped for 1e-3 here; a single small world cannot deliver that in any float32 arithmetic: one
+    flipped tie (0.005 % of the cells per step, test below) is amplified by the pattern-forming dynamics.
+    What float32 does deliver is the ENSEMBLE statistics - next test.  Cell-wise long-horizon equality is
+    not claimed for this mode; it is what the default (exact) mode is for."""
     g = golden("G2_c1_trajectory")
     eng = _engine(amd, 1, 64, 64, 0, "fast")
     eng.upload_state(g["light0"], g["dark0"])
@@ -248,6 +254,46 @@ def test_c1_trajectory_fast_mode_statistics(amd, golden):
         worst = max(worst, abs(ml - g["mean_light"][t]), abs(md - g["mean_dark"][t]))
     assert worst < 5e-3, worst
     eng.close()
+
+
+def test_fast_mode_tolerance_on_developed_states_over_the_ramp(amd):
+    """The stated float32 tolerance, on DEVELOPED states over the whole luminosity ramp, as measured
+    by tools/fast_tolerance.py (profiles/r02_fast_tolerance.json: 64 worlds of 256x256, 512 steps):
+      * per step, from identical states: every cell within one quantum and >= 99.99 % of the cells identical
+        (measured: at most 0.0056 % differ, at t = 360; SURVEY asks for >= 99.95 %);
+      * trajectory: the ensemble means of light and dark stay within 3e-4 of the exact mode's at every step
+        (measured 1.5e-4 / 8e-6; SURVEY asks for 1e-3).
+    Both asserted at (measured x 2).  The exact engine's states ARE the float64 reference's (soak test)."""
+    B, G, steps, every = 64, 256, 512, 8
+    ex, fs, ft = (_engine(amd, B, G, G, 0, m) for m in ("exact", "fast", "fast"))
+    ex.init_random(42)
+    ft.init_random(42)                                       # walks the ramp on its own
+    L, dL = 0.75, 0.75 / 512
+    n = float(B) * G * G * 1000.0
+    worst_frac, worst_q, drift = 0.0, 0, 0.0
+    for t in range(steps):
+        sample = t > 0 and t % every == 0
+        if sample:
+            sl, sd = ex.download_planes()
+            fs.upload_state_f32(sl.astype(np.float32), sd.astype(np.float32), quantised=True)
+        ex.step(L)
+        ft.step(L)
+        if sample:
+            fs.step(L)
+            rl, rd = (_k(x) for x in ex.download_planes())
+            fl, fd = (_k(x) for x in fs.download_planes())
+            dl, dd = np.abs(fl - rl), np.abs(fd - rd)
+            worst_q = max(worst_q, int(dl.max()), int(dd.max()))
+            worst_frac = max(worst_frac, (np.count_nonzero(dl) + np.count_nonzero(dd)) / (2.0 * dl.size))
+        se, sf = ex.reduce(), ft.reduce()
+        drift = max(drift, abs(float(sf["sum_light_k"].sum()) - float(se["sum_light_k"].sum())) / n,
+                    abs(float(sf["sum_dark_k"].sum()) - float(se["sum_dark_k"].sum())) / n)
+        L = min(max(L + dL, 0.75), 1.5)
+    assert worst_q <= 1, worst_q
+    assert worst_frac <= 1.2e-4, worst_frac                 # >= 99.988 % identical (measured 99.9944 %)
+    assert drift <= 3e-4, drift
+    for e in (ex, fs, ft):
+        e.close()
 
 
 def test_multiworld_trajectory_vs_c_oracle(amd):
@@ -761,7 +807,7 @@ def test_run_episode_matches_stepwise_engine(amd, B, H, W):
 @pytest.mark.parametrize("B,H,W,N", [(3, 64, 256, 5), (2, 130, 520, 3), (6, 32, 64, 4), (33, 8, 8, 6), (1, 70, 320, 16)])
 @pytest.mark.parametrize("precision", ["exact", "fast"])
 @pytest.mark.parametrize("policy", ["argmax", "argmin_with_random_steps", "mixed_table"])
-@pytest.mark.parametrize("K", [5, 11])       # 2 / 5 pairs: float32 -> binary16 -> (binary16 ->)* float32 planes
+@pytest.mark.parametrize("K", [5, 11])       # 2 / 5 step pairs + the closing single step
 def test_agent_step_pairs_equal_single_steps(amd, monkeypatch, B, H, W, N, precision, policy, K):
     """dw_run_episode without per-step world flags runs step PAIRS as one fused launch and patches the
     agents' in-between step in (policy from recomputed step-1 values, grazing in agent order, 3x3 blocks
@@ -885,7 +931,7 @@ def test_c1_trajectory_via_episode_kernel_g2(amd, golden):
                                    (2, 3, 256), (1, 5, 500), (1, 65, 260),
                                    (5, 64, 64), (3, 40, 128), (33, 8, 8), (2, 130, 32), (17, 16, 16),   # packed
                                    (3, 70, 96), (5, 20, 100), (2, 66, 192)])          # packed, W does not divide 256
-@pytest.mark.parametrize("nsteps", [3, 5, 8, 13])        # 1, 2, 3, 6 fused launches: every float32 / binary16 plane variant
+@pytest.mark.parametrize("nsteps", [3, 5, 8, 13])        # 1, 2, 3, 6 fused launches
 @pytest.mark.parametrize("precision", ["fast", "exact"])
 def test_fused_step_pairs_equal_single_steps(amd, monkeypatch, B, H, W, nsteps, precision):
     """dw_step_n fuses pairs of steps in one kernel (step_stream_fused2[_exact]): the result must be
@@ -914,44 +960,101 @@ def test_fused_step_pairs_equal_single_steps(amd, monkeypatch, B, H, W, nsteps, 
     assert np.array_equal(a[4], b[4])
 
 
-@pytest.mark.parametrize("B,H,W", [(2, 100, 256), (1, 70, 320), (9, 40, 64)])
-@pytest.mark.parametrize("precision", ["fast", "exact"])
-def test_binary16_intermediate_planes_are_lossless(amd, monkeypatch, B, H, W, precision):
-    """dw_step_n keeps the states between its fused launches as binary16 planes (every quantised value is
-    an integer <= 1000, exact in binary16): same planes, previous planes and reductions as with float32
-    intermediates (DW_NO_F16), also with the exact mode's overflow fallbacks forced, which patch the
-    binary16 output cell by cell."""
-    monkeypatch.setenv("DW_NO_EPISODE_KERNEL", "1")
-    for caps in (None, ("2", "0")):
-        if caps and precision == "fast":
-            continue
-        outs = []
-        for f16 in (True, False):
-            monkeypatch.delenv("DW_NO_F16", raising=False)
-            if not f16:
-                monkeypatch.setenv("DW_NO_F16", "1")
-            if caps:
-                monkeypatch.setenv("DW_TEST_QUEUE_CAP", caps[0])
-                monkeypatch.setenv("DW_TEST_MISMATCH_CAP", caps[1])
-            eng = _engine(amd, B, H, W, 0, precision)
-            assert ("binary16" in eng.kernel_info()) == f16
-            eng.init_random(11)
-            L = eng.step_n(11, 0.95, 0.006, 0.75, 1.5)
-            outs.append((L, eng.download_planes(), eng.download_planes(1), eng.reduce()))
-            eng.close()
-        monkeypatch.delenv("DW_TEST_QUEUE_CAP", raising=False)
-        monkeypatch.delenv("DW_TEST_MISMATCH_CAP", raising=False)
-        a, b = outs
-        assert a[0] == b[0]
-        assert np.array_equal(a[1][0], b[1][0]) and np.array_equal(a[1][1], b[1][1])
-        assert np.array_equal(a[2][0], b[2][0]) and np.array_equal(a[2][1], b[2][1])
-        for f in ("max_k", "sum_light_k", "sum_dark_k"):
-            assert np.array_equal(a[3][f], b[3][f])
+@pytest.mark.parametrize("B,H,W", [(2, 100, 256), (1, 70, 320), (9, 40, 64), (3, 12, 12)])
+def test_binary16_planes_are_lossless(amd, B, H, W):
+    """The canonical plane format is binary16 per-mille (csrc/dw_common.hpp: every quantised value is an
+    integer in [0, 1000], binary16 holds the integers up to 2048 exactly): every value 0..1000 goes through
+    upload -> device planes -> download unchanged, as float64 k/1000 bit for bit; and a state stepped in
+    exact mode equals the C oracle fed the same values (every kernel reads the planes it wrote)."""
+    rng = np.random.RandomState(H)
+    # every value 0..1000 at random positions (a REGULAR pattern - e.g. a linear ramp with bare = 0 - makes the
+    # float64 pre-rounding values exact rounding ties, x.5, which no two evaluation orders round alike: the
+    # reference's own FFT noise decides them; see the header of include/daisyworld_hip.h)
+    light = rng.permutation(np.arange(B * H * W) % 1001).reshape(B, H, W).astype(np.float64)
+    dark = np.floor(rng.rand(B, H, W) * (1001.0 - light)).astype(np.float64)
+    assert set(np.unique(light)) == set(range(1001)) or light.size < 1001
+    eng = _engine(amd, B, H, W, 0, "exact")
+    eng.upload_state_f32((light / 1000.0).astype(np.float32), (dark / 1000.0).astype(np.float32), quantised=True)
+    gl, gd = eng.download_planes()
+    assert np.array_equal(gl, light / 1000.0) and np.array_equal(gd, dark / 1000.0)
+    s = eng.reduce()
+    assert np.array_equal(s["sum_light_k"], light.sum(axis=(1, 2)).astype(np.uint64))
+    assert np.array_equal(s["max_k"], np.maximum(light.max(axis=(1, 2)), dark.max(axis=(1, 2))).astype(np.uint32))
+    eng.step(1.0)
+    ref = c_oracle.forward(light / 1000.0, dark / 1000.0, 1.0)
+    kl, kd = (_k(x) for x in eng.download_planes())
+    assert np.array_equal(kl, _k(ref[:, 1])) and np.array_equal(kd, _k(ref[:, 2]))
+    pl, pd = eng.download_planes(1)
+    assert np.array_equal(pl, light / 1000.0) and np.array_equal(pd, dark / 1000.0)
+    eng.close()
+
+
+@pytest.mark.parametrize("precision", ["exact", "fast"])
+@pytest.mark.parametrize("source", ["f64", "f32", "philox"])
+def test_unquantised_initial_state_lives_in_its_upload_format(amd, precision, source):
+    """An un-quantised state (the reference's initialize_grid does not round) cannot live in binary16 planes:
+    it stays float64 / float32 until the first step has read it, then one more step as the previous state.
+    Downloads, reductions, grazing, observations and the greedy policy see it in full precision; the first
+    step equals the float64 oracle on exactly those values (exact mode) / is within tolerance (fast)."""
+    B, G, N = 3, 48, 2
+    rng = np.random.RandomState(17)
+    light = (rng.rand(B, G, G) < 0.33) * 0.2 * rng.rand(B, G, G)
+    dark = (rng.rand(B, G, G) < 0.33) * 0.2 * rng.rand(B, G, G)
+    eng = _engine(amd, B, G, G, N, precision)
+    if source == "f64":
+        eng.upload_state(light, dark)
+    elif source == "f32":
+        eng.upload_state_f32(light.astype(np.float32), dark.astype(np.float32), quantised=False)
+    else:
+        eng.init_random(4)
+    idx = rng.randint(G, size=(B, N, 2))
+    eng.upload_agents(idx, np.ones((B, N)))
+    gl, gd = eng.download_planes()
+    if source == "f64":
+        assert np.array_equal(gl, light) and np.array_equal(gd, dark)
+    elif source == "f32":                                   # per-mille float32 on the device
+        np.testing.assert_allclose(gl, light, rtol=3e-7, atol=0)
+    assert (gl * 1000 != np.rint(gl * 1000)).any()          # really un-quantised
+    from therldaisyworld_amd import _ffi
+    with pytest.raises(_ffi.DaisyHipError):
+        eng.device_planes()                                 # no binary16 planes before the first step
+    with pytest.raises(_ffi.DaisyHipError):
+        eng.snapshot_save()
+    env = O.OracleDaisyWorld(grid_dimension=G, n_agents=N, batch_size=B)
+    env.L = 0.9
+    env.set_initial_cover(gl.copy(), gd.copy())
+    env.agent_indices = idx.astype(np.int64)
+    env.agent_states = np.ones((B, N, 1))
+    np.testing.assert_allclose(eng.get_obs(0.9), env.get_obs(env.agent_indices), rtol=1e-12, atol=0)
+    a = rng.randint(5, 9, size=(B, N, 1))                   # grazing actions: eat un-quantised covers
+    obs, reward, done = eng.env_step(0.9, a)
+    robs, rreward, rdone, _ = env.step(a)
+    idx2, st2 = eng.download_agents()
+    assert np.array_equal(idx2, env.agent_indices)
+    kl, kd = (_k(x) for x in eng.download_planes())
+    if precision == "exact":
+        assert np.array_equal(st2[..., None], env.agent_states)
+        assert np.array_equal(kl, _k(env.grid[:, 1])) and np.array_equal(kd, _k(env.grid[:, 2]))
+        assert np.array_equal(obs, robs) and np.array_equal(reward, rreward) and np.array_equal(done, rdone)
+        pl, pd = eng.download_planes(1)                     # the grazed un-quantised state is the previous state
+        assert np.array_equal(pl[np.arange(B)[:, None], env.agent_indices[..., 0], env.agent_indices[..., 1]], np.zeros((B, N)))
+    else:
+        assert np.abs(kl - _k(env.grid[:, 1])).max() <= 1 and np.abs(kd - _k(env.grid[:, 2])).max() <= 1
+    eng.step(0.91, np.zeros((B, N, 1), dtype=int))          # second step: binary16 planes on both sides
+    env.L = 0.91
+    env.step(np.zeros((B, N, 1), dtype=int))
+    if precision == "exact":
+        kl, kd = (_k(x) for x in eng.download_planes())
+        assert np.array_equal(kl, _k(env.grid[:, 1])) and np.array_equal(kd, _k(env.grid[:, 2]))
+        assert np.array_equal(eng.get_obs(), env.get_obs(env.agent_indices))
+    eng.device_planes()
+    eng.close()
 
 
 def test_fused_fast_trajectory_vs_oracle_tolerance(amd):
-    """Fused float32 stepping against the float64 C oracle from the same state: after 2 steps every
-    cell within 2 quanta and >= 99 % identical (each fused step has the single-step fast tolerance)."""
+    """Fused float32 stepping against the float64 C oracle from the same developed state: after 3 steps (a
+    fused pair + one single step) every cell within 2 quanta and >= 99.94 % identical - measured 0.029 %
+    differing, all by one quantum (profiles/r02_fast_tolerance_cases.json); asserted at twice that."""
     B, H, W = 2, 256, 256
     eng = _engine(amd, B, H, W, 0, "fast")
     eng.init_random(3)
@@ -963,8 +1066,8 @@ def test_fused_fast_trajectory_vs_oracle_tolerance(amd):
     gl, gd = eng.download_planes()
     assert L1 == Lo
     dl, dd = np.abs(_k(gl) - _k(light)), np.abs(_k(gd) - _k(dark))
-    assert dl.max() <= 3 and dd.max() <= 3
-    assert 1.0 - (np.count_nonzero(dl) + np.count_nonzero(dd)) / (2.0 * dl.size) >= 0.985
+    assert dl.max() <= 2 and dd.max() <= 2
+    assert (np.count_nonzero(dl) + np.count_nonzero(dd)) / (2.0 * dl.size) <= 6e-4
     eng.close()
 
 

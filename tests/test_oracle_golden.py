@@ -242,7 +242,7 @@ def test_c_oracle_row_parallel_mode_equals_world_parallel_mode():
     the same cells by the same expressions."""
     from oracle import c_oracle
     rng = np.random.RandomState(4)
-    B, H, W = 2, 256, 256                               # H*W = 2^16 and B < threads: the row-parallel path
+    B, H, W = 2, 512, 1024                              # H*W = 2^19 and B < threads: the row-parallel path
     light = np.rint(rng.rand(B, H, W) * 400) / 1000
     dark = np.rint(rng.rand(B, H, W) * 400) / 1000
     nthreads = c_oracle.max_threads()

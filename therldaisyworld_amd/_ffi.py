@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DW_LIB", os.path.join(_HERE, "libdaisyworld_hip.so"))   # DW_LIB: tuning builds
 
-DW_ABI_VERSION = 1
+DW_ABI_VERSION = 2
 DW_OK, DW_EINVAL, DW_ENODEVICE, DW_ENOMEM, DW_EHIP, DW_ESTATE = 0, -1, -2, -3, -4, -5
 PRECISION = {"exact": 0, "fast": 1, "f64": 2}
 STATE_CURRENT, STATE_PREVIOUS = 0, 1
@@ -72,6 +72,7 @@ SIGNATURES = {
     "dw_upload_actions": (C.c_int, [_vp, _pi]),
     "dw_download_actions": (C.c_int, [_vp, _pi]),
     "dw_step_n": (C.c_int, [_vp, _i32, _pd, _dbl, _dbl, _dbl, C.c_int]),
+    "dw_last_step_n_timing": (C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(_i32), C.POINTER(_i32)]),
     "dw_update_agents": (C.c_int, [_vp, _pi, _i32, _i32]),
     "dw_forward_f64": (C.c_int, [_vp, _pd, _pd, _dbl, _pd, _pd, _pd, _pd, _pd]),
     "dw_get_obs": (C.c_int, [_vp, _dbl, _pd]),

@@ -9,13 +9,11 @@ namespace dw {
 // agents_update — ref update_agents (daisy_world_rl.py:181-244), collision_mode 0.
 // One thread per world walks its agents IN ORDER (the first agent to land on a cell eats it all).
 // Energy stores are float64 and updated with exactly the reference's operations, so alive/dead
-// decisions and rewards are bit-identical.  `f64L/f64D` (natural units) are the exact copies of an
-// un-quantised initial state when present (else nullptr).
+// decisions and rewards are bit-identical.
 // ---------------------------------------------------------------------------------------------
-// T: float32 planes, or the binary16 planes between the step pairs of one dw_run_episode call.
+// T: the format of the CURRENT state (dw_common.hpp): plane_t, or float / double before the first step.
 template <typename T>
-__global__ void agents_update(T* __restrict__ L32, T* __restrict__ D32,
-                              double* __restrict__ f64L, double* __restrict__ f64D,
+__global__ void agents_update(T* __restrict__ L, T* __restrict__ D,
                               int* __restrict__ idx, double* __restrict__ st,
                               const int* __restrict__ action, int act_b, int act_n, int B, int N,
                               int H, int W, double agent_gamma, int do_clip,
@@ -40,11 +38,9 @@ __global__ void agents_update(T* __restrict__ L32, T* __restrict__ D32,
                 idx[((size_t)b * N + n) * 2 + 1] = c;
                 if (a > 4) {                                                     // ref :210-216
                     const size_t o = woff + (size_t)r * W + c;
-                    double l, d;
-                    if (f64L) { l = f64L[o]; d = f64D[o]; f64L[o] = 0.0; f64D[o] = 0.0; }
-                    else { l = (double)(float)L32[o] / 1000.0; d = (double)(float)D32[o] / 1000.0; }
+                    const double l = to_natural(L[o]), d = to_natural(D[o]);
                     s += l + d;
-                    L32[o] = (T)0.f; D32[o] = (T)0.f;
+                    L[o] = (T)0.f; D[o] = (T)0.f;
                     st[(size_t)b * N + n] = s;
                 }
             }
@@ -83,7 +79,7 @@ __global__ void reward_done(const double* __restrict__ st, double* __restrict__ 
 // ---------------------------------------------------------------------------------------------
 template <typename PrevT, bool POST>
 __global__ void observe(const PrevT* __restrict__ pL, const PrevT* __restrict__ pD,
-                        const float* __restrict__ cL, const float* __restrict__ cD,
+                        const plane_t* __restrict__ cL, const plane_t* __restrict__ cD,
                         const int* __restrict__ idx, const double* __restrict__ st, int B, int N,
                         int H, int W, PhysF64 P, int mask, double* __restrict__ obs,
                         double* __restrict__ reward = nullptr, unsigned char* __restrict__ done = nullptr) {
@@ -113,8 +109,8 @@ __global__ void observe(const PrevT* __restrict__ pL, const PrevT* __restrict__ 
     double v[7];
     if (POST) {
         v[0] = dw_round3_k(P.p - o.nl - o.nd) / 1000.0;
-        v[1] = (double)cL[woff + (size_t)r * W + c] / 1000.0;
-        v[2] = (double)cD[woff + (size_t)r * W + c] / 1000.0;
+        v[1] = to_natural(cL[woff + (size_t)r * W + c]);
+        v[2] = to_natural(cD[woff + (size_t)r * W + c]);
         v[3] = dw_round3_k(o.T) / 1000.0;
         v[4] = dw_round3_k(o.Tl) / 1000.0;
         v[5] = dw_round3_k(o.Td) / 1000.0;
@@ -171,7 +167,7 @@ __global__ void policy_greedy(const T* __restrict__ cL, const T* __restrict__ cD
         if ((mask >> k) & 1) {
             const int r = (ar + (k / 3 - 1) + H) % H, c = (ac + (k % 3 - 1) + W) % W;
             const size_t o = woff + (size_t)r * W + c;
-            v = (double)(float)cL[o] / 1000.0 + (double)(float)cD[o] / 1000.0;
+            v = to_natural(cL[o]) + to_natural(cD[o]);
         }
         if (i == 0 || (argmin ? v < bestv : v > bestv)) { best = i; bestv = v; }
     }

@@ -59,8 +59,8 @@ __device__ inline unsigned int fast_word_from9(const unsigned int* w, const Phys
 }
 
 struct LookaheadArgs {
-    const float* inL; const float* inD;          // S0': the state the fused launch read     } float32 or binary16
-    float* outL; float* outD;                    // S2 written by the fused launch, patched here } planes (TI / TO)
+    const plane_t* inL; const plane_t* inD;      // S0': the state the fused launch read
+    plane_t* outL; plane_t* outD;                // S2 written by the fused launch, patched here
     int* idx; double* st;                        // agents after step t, updated to step t+1
     const signed char* code;                     // [B][N] for step t+1: 0..8 action, -1 greedy argmax, -2 argmin
     unsigned char* agent_ok;                     // [B][N] reward >= 0.1 after step t+1, or null
@@ -74,8 +74,10 @@ struct LookaheadArgs {
     PhysF64 P64; double La, Lb;                  // float64 constants and the two luminosities (exact mode)
 };
 
-template <bool EXACT, typename TI = float, typename TO = float>
+template <bool EXACT>
 __global__ __launch_bounds__(64) void agents_lookahead_patch(LookaheadArgs A) {
+    using TI = plane_t;
+    using TO = plane_t;
     __shared__ unsigned int s_s1[kLookaheadMaxAgents][5];      // S1 at centre, (r,c-1), (r-1,c), (r+1,c), (r,c+1)
     __shared__ int s_act[kLookaheadMaxAgents];
     __shared__ int s_gr[kLookaheadMaxAgents], s_gc[kLookaheadMaxAgents];
@@ -83,10 +85,10 @@ __global__ __launch_bounds__(64) void agents_lookahead_patch(LookaheadArgs A) {
     const int b = blockIdx.x, lane = threadIdx.x;
     const int N = A.N, H = A.H, W = A.W;
     const size_t woff = (size_t)b * H * W;
-    const TI* pL = reinterpret_cast<const TI*>(A.inL) + woff;
-    const TI* pD = reinterpret_cast<const TI*>(A.inD) + woff;
-    TO* const oL = reinterpret_cast<TO*>(A.outL);
-    TO* const oD = reinterpret_cast<TO*>(A.outD);
+    const TI* pL = A.inL + woff;
+    const TI* pD = A.inD + woff;
+    TO* const oL = A.outL;
+    TO* const oD = A.outD;
     PhysF64 Pa = A.P64, Pb = A.P64;
     Pa.L = A.La;
     Pb.L = A.Lb;

@@ -1,9 +1,10 @@
 // dw_api.hip — C ABI (include/daisyworld_hip.h) over the gfx950 kernels in dw_kernels.hpp.
 //
-// Host-side responsibilities: device state (ping-pong per-mille planes, agents, reductions),
+// Host-side responsibilities: device state (ping-pong binary16 per-mille planes, agents, reductions),
 // per-step derivation of the float32 coefficient set from the float64 constants and the current
-// luminosity, kernel selection by grid shape, and the bookkeeping of which retained state is
-// quantised / has an exact float64 copy.  No CPU compute path exists here.
+// luminosity, kernel selection by grid shape, and the bookkeeping of the un-quantised initial state
+// (float64 or float32 buffers that live until the first step has consumed them).  No CPU compute path
+// exists here.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -48,21 +49,30 @@ static int fail(int code, const char* fmt, ...) {
 // ------------------------------------------------------------------------------------------------
 // handle
 // ------------------------------------------------------------------------------------------------
-enum F64Owner { F64_NONE = 0, F64_CUR = 1, F64_PREV = 2 };
+// An un-quantised state (the reference's initialize_grid does not round, ref :285-324) cannot live in the
+// canonical binary16 planes.  It is held in its upload format - float64 natural units (dw_upload_state_f64) or
+// float32 per-mille (dw_init_random, dw_upload_state_f32 with quantised = 0) - and is the CURRENT state until
+// the first step has read it, then for one more step the PREVIOUS state (observations and the materialised
+// grid derive their temperature channels from the pre-step state).  While it is the current state the
+// binary16 planes of the `cur` buffer are undefined.
+enum UnqKind { UNQ_F64 = 1, UNQ_F32 = 2 };
+enum UnqOwner { OWN_NONE = 0, OWN_CUR = 1, OWN_PREV = 2 };
 
 struct dw_handle {
     dw_params prm;
     hipStream_t stream = nullptr;
     bool own_stream = false;
     size_t cells = 0;                 // B*H*W
-    float* L32[2] = {nullptr, nullptr};
-    float* D32[2] = {nullptr, nullptr};
+    plane_t* L16[2] = {nullptr, nullptr};   // canonical planes (binary16 per-mille integers), ping-pong
+    plane_t* D16[2] = {nullptr, nullptr};
     int cur = 0;
-    double* L64 = nullptr;            // exact natural-unit copy of an un-quantised upload
+    double* L64 = nullptr;            // un-quantised state, float64 natural units (lazily allocated, kept)
     double* D64 = nullptr;
-    F64Owner f64 = F64_NONE;
+    float* U32L = nullptr;            // un-quantised state, float32 per-mille (lazily allocated; freed again
+    float* U32D = nullptr;            //   after use when it is large, see release_unquantised)
+    UnqKind unq_kind = UNQ_F64;
+    UnqOwner unq = OWN_NONE;
     bool have_state = false;
-    bool cur_quantised = false;
     bool stepped = false;             // prev/cur form a forward() pair
     double L_last = 0.0;              // luminosity of the last forward()
     int* idx = nullptr;               // [B][N][2]
@@ -83,8 +93,7 @@ struct dw_handle {
     // streaming kernel (W >= 256)
     bool use_stream = false;
     StripGeom sgeom{};
-    bool allow_fuse = false;          // float32-only mode on wide grids: dw_step_n fuses pairs of steps
-    bool allow_f16 = false;           // dw_step_n keeps the states between its fused launches as binary16 planes
+    bool allow_fuse = false;          // wide grids: dw_step_n / dw_run_episode fuse pairs of steps
     FusedGeom fgeom{};
     int* done_at = nullptr;           // [B]
     int* agents_done_at = nullptr;    // [B][N]
@@ -96,25 +105,60 @@ struct dw_handle {
     double* reward_d = nullptr;       // [B][N]
     unsigned char* done_d = nullptr;  // [B][N]
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t evf0 = nullptr, evf1 = nullptr;   // around the fused launches of the last dw_step_n call
+    int fused_launches = 0;           // ... and how many there were (dw_last_step_n_timing)
+    StatsDev* side_stats = nullptr;   // reductions of dw_forward_f64's side computation (not the handle's)
     unsigned char* pinned = nullptr;  // page-locked host staging of dw_env_step (actions in, obs/reward/done out)
     size_t pinned_bytes = 0;
     // dw_snapshot_save / dw_snapshot_restore: device copy of the current state
-    float* snapL = nullptr;
-    float* snapD = nullptr;
-    float* snapPL = nullptr;          // the retained previous state (observations, caches) when there is one
-    float* snapPD = nullptr;
+    plane_t* snapL = nullptr;
+    plane_t* snapD = nullptr;
+    plane_t* snapPL = nullptr;        // the retained previous state (observations, caches) when there is one
+    plane_t* snapPD = nullptr;
     bool snap_stepped = false;
     double snap_L_last = 0.0;
-    F64Owner snap_f64 = F64_NONE;
+    UnqOwner snap_unq = OWN_NONE;
     int* snap_idx = nullptr;
     double* snap_st = nullptr;
     unsigned char* snap_stats = nullptr;
-    bool snap_valid = false, snap_quantised = false, snap_agents = false;
+    bool snap_valid = false, snap_agents = false;
     // kernel selection
     int tcq = 0, rpt = 0;             // 0 => generic
     Geom geom{};
     size_t tile_lds = 0;
 };
+
+static inline bool cur_quantised(const dw_handle* h) { return h->unq != OWN_CUR; }
+
+// Asynchronous copies FROM host memory (the caller's arrays, local vectors) must have finished before that
+// memory can go away: a function that issues them declares one of these right after the host buffers, so that
+// every early return (HIPCHK / NEED) waits for the stream first.  disarm() after the function's own final
+// synchronisation.
+struct SyncOnExit {
+    hipStream_t stream;
+    bool armed = true;
+    explicit SyncOnExit(hipStream_t s) : stream(s) {}
+    ~SyncOnExit() { if (armed) (void)hipStreamSynchronize(stream); }
+    void disarm() { armed = false; }
+};
+
+// the un-quantised float32 buffers are as large as all four canonical planes together: give them back once
+// nothing refers to them any more if they are big (the north-star shape: 128 GiB)
+static void release_unquantised(dw_handle* h) {
+    if (h->unq != OWN_NONE || !h->U32L) return;
+    if (h->snap_valid && h->snap_unq == OWN_PREV) return;        // a snapshot's previous state lives there
+    if (h->cells * 2 * sizeof(float) < ((size_t)1 << 30)) return;
+    (void)hipStreamSynchronize(h->stream);
+    (void)hipFree(h->U32L); (void)hipFree(h->U32D);
+    h->U32L = nullptr; h->U32D = nullptr;
+}
+
+static int ensure_u32(dw_handle* h) {
+    if (h->U32L) return DW_OK;
+    HIPCHK(hipMalloc(&h->U32L, sizeof(float) * h->cells));
+    HIPCHK(hipMalloc(&h->U32D, sizeof(float) * h->cells));
+    return DW_OK;
+}
 
 static int run_episode_impl(dw_handle* h, int32_t nsteps, const double* L_schedule, int policy_mode,
                             const uint8_t* use_table, const int8_t* table, uint32_t threshold_k,
@@ -313,7 +357,6 @@ static void select_kernel(dw_handle* h) {
             if (v >= 0 && v < kMismatchCap) mcap = v;
         }
         h->allow_fuse = !std::getenv("DW_NO_FUSE");
-        h->allow_f16 = !std::getenv("DW_NO_F16");
         FusedGeom& f = h->fgeom;
         f.B = p.batch; f.H = p.height; f.W = p.width;
         f.SR = g.SR;
@@ -354,7 +397,7 @@ static void select_kernel(dw_handle* h) {
 }
 
 template <int TCQ, int RPT, bool EXACT>
-static int launch_tiled(dw_handle* h, const float* iL, const float* iD, float* oL, float* oD,
+static int launch_tiled(dw_handle* h, const plane_t* iL, const plane_t* iD, plane_t* oL, plane_t* oD,
                         const PhysF32& P, const PhysF64& P64, StatsDev* stats,
                         unsigned long long* fixups, unsigned long long* zero_me, int zero_n, const FixQ& fq) {
     auto kern = step_tiled<TCQ, RPT, EXACT>;
@@ -400,14 +443,13 @@ static int launch_forward(dw_handle* h, double L) {
     fq.redo_tiles = h->redo_tiles;
     const dim3 ggrid((unsigned)((p.height * p.width + 255) / 256), (unsigned)p.batch);
     int prec = p.precision;
-    if (prec == DW_PRECISION_EXACT && !h->cur_quantised) prec = DW_PRECISION_F64;  // first step
 #ifdef DW_TUNING
     if (const char* e = std::getenv("DW_ABLATE")) {
         if (std::strcmp(e, "copy") == 0) {
-            const size_t n4 = h->cells / 4;
+            const size_t n4 = h->cells * sizeof(plane_t) / 16;
             hipLaunchKernelGGL(copy_planes, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, h->stream,
-                               reinterpret_cast<const float4*>(h->L32[in]), reinterpret_cast<const float4*>(h->D32[in]),
-                               reinterpret_cast<float4*>(h->L32[out]), reinterpret_cast<float4*>(h->D32[out]), n4);
+                               reinterpret_cast<const float4*>(h->L16[in]), reinterpret_cast<const float4*>(h->D16[in]),
+                               reinterpret_cast<float4*>(h->L16[out]), reinterpret_cast<float4*>(h->D16[out]), n4);
             HIPCHK(hipGetLastError());
             h->cur = out; h->sp = 1 - h->sp; h->stepped = true; h->L_last = L;
             return DW_OK;
@@ -416,24 +458,21 @@ static int launch_forward(dw_handle* h, double L) {
         HIPCHK(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_ablate), &v, sizeof(int), 0, hipMemcpyHostToDevice, h->stream));
     }
 #endif
-    if (prec == DW_PRECISION_F64) {
-        if (h->f64 == F64_CUR)
-            hipLaunchKernelGGL((step_generic<double, 2>), ggrid, dim3(256), 0, h->stream, h->L64, h->D64,
-                               h->L32[out], h->D32[out], p.height, p.width, P, P64, stats, fixups, zero_me, zero_n);
-        else
-            hipLaunchKernelGGL((step_generic<float, 2>), ggrid, dim3(256), 0, h->stream, h->L32[in],
-                               h->D32[in], h->L32[out], h->D32[out], p.height, p.width, P, P64, stats,
-                               fixups, zero_me, zero_n);
+    if (h->unq == OWN_CUR) {
+        // first step from an un-quantised state: one thread per cell straight from the upload format, in
+        // float64 (exact and f64 modes: bit-identical to the reference's first step) or float32 (fast mode)
+#define DW_GEN(T, PR, IL, ID)                                                                                     \
+    hipLaunchKernelGGL((step_generic<T, PR>), ggrid, dim3(256), 0, h->stream, IL, ID, h->L16[out], h->D16[out],   \
+                       p.height, p.width, P, P64, stats, fixups, zero_me, zero_n)
+        const bool f32arith = prec == DW_PRECISION_FAST;
+        if (h->unq_kind == UNQ_F64) { if (f32arith) DW_GEN(double, 1, h->L64, h->D64); else DW_GEN(double, 2, h->L64, h->D64); }
+        else { if (f32arith) DW_GEN(float, 1, h->U32L, h->U32D); else DW_GEN(float, 2, h->U32L, h->U32D); }
         HIPCHK(hipGetLastError());
-    } else if (h->tcq == 0 && !h->use_stream) {
-        if (prec == DW_PRECISION_EXACT)
-            hipLaunchKernelGGL((step_generic<float, 0>), ggrid, dim3(256), 0, h->stream, h->L32[in],
-                               h->D32[in], h->L32[out], h->D32[out], p.height, p.width, P, P64, stats,
-                               fixups, zero_me, zero_n);
-        else
-            hipLaunchKernelGGL((step_generic<float, 1>), ggrid, dim3(256), 0, h->stream, h->L32[in],
-                               h->D32[in], h->L32[out], h->D32[out], p.height, p.width, P, P64, stats,
-                               fixups, zero_me, zero_n);
+    } else if (prec == DW_PRECISION_F64 || (h->tcq == 0 && !h->use_stream)) {
+        if (prec == DW_PRECISION_F64) DW_GEN(plane_t, 2, h->L16[in], h->D16[in]);
+        else if (prec == DW_PRECISION_EXACT) DW_GEN(plane_t, 0, h->L16[in], h->D16[in]);
+        else DW_GEN(plane_t, 1, h->L16[in], h->D16[in]);
+#undef DW_GEN
         HIPCHK(hipGetLastError());
     } else if (h->use_stream) {
         const bool ex = prec == DW_PRECISION_EXACT;
@@ -441,10 +480,10 @@ static int launch_forward(dw_handle* h, double L) {
         const dim3 grid((unsigned)g.chunk * 8u);
         const int halo = p.width < 256 ? 3 : (p.width == 256 ? 0 : (p.width % 256 == 0 ? 1 : 2));
 #define DW_STREAM(K, HL)                                                                                \
-    hipLaunchKernelGGL((K<HL>), grid, dim3(256), 0, h->stream, h->L32[in], h->D32[in], h->L32[out],     \
-                       h->D32[out], g, P, P64, stats, fixups, zero_me, zero_n)
+    hipLaunchKernelGGL((K<HL>), grid, dim3(256), 0, h->stream, h->L16[in], h->D16[in], h->L16[out],     \
+                       h->D16[out], g, P, P64, stats, fixups, zero_me, zero_n)
         if (ex) {
-            const StreamExactArgs A{h->L32[in], h->D32[in], h->L32[out], h->D32[out], g, P, stats, fixups, zero_me,
+            const StreamExactArgs A{h->L16[in], h->D16[in], h->L16[out], h->D16[out], g, P, stats, fixups, zero_me,
                                     zero_n, P64};
             if (halo == 0) hipLaunchKernelGGL((step_stream_exact<0>), grid, dim3(256), 0, h->stream, A);
             else if (halo == 1) hipLaunchKernelGGL((step_stream_exact<1>), grid, dim3(256), 0, h->stream, A);
@@ -462,9 +501,9 @@ static int launch_forward(dw_handle* h, double L) {
         const bool ex = prec == DW_PRECISION_EXACT;
         int rc;
 #define DW_TILED(T, R)                                                                              \
-    rc = ex ? launch_tiled<T, R, true>(h, h->L32[in], h->D32[in], h->L32[out], h->D32[out], P, P64,  \
+    rc = ex ? launch_tiled<T, R, true>(h, h->L16[in], h->D16[in], h->L16[out], h->D16[out], P, P64,  \
                                        stats, fixups, zero_me, zero_n, fq)                           \
-            : launch_tiled<T, R, false>(h, h->L32[in], h->D32[in], h->L32[out], h->D32[out], P, P64, \
+            : launch_tiled<T, R, false>(h, h->L16[in], h->D16[in], h->L16[out], h->D16[out], P, P64, \
                                         stats, fixups, zero_me, zero_n, fq)
         if (h->tcq == 64 && h->rpt == 8) { DW_TILED(64, 8); }
         else if (h->tcq == 64 && h->rpt == 4) { DW_TILED(64, 4); }
@@ -476,20 +515,18 @@ static int launch_forward(dw_handle* h, double L) {
     }
     h->cur = out;
     h->sp = 1 - h->sp;
-    h->f64 = (h->f64 == F64_CUR) ? F64_PREV : F64_NONE;
-    h->cur_quantised = true;
+    h->unq = (h->unq == OWN_CUR) ? OWN_PREV : OWN_NONE;
     h->stepped = true;
     h->L_last = L;
+    release_unquantised(h);
     return DW_OK;
 }
 
-// Two steps (luminosities L1 then L2) in one launch: float32-only mode, wide grids, no agent update in
-// between.  The buffer that held the input now holds the state TWO steps back, so the retained
-// "previous state" is not valid afterwards; dw_step_n always ends with an ordinary single step.
-// in16 / out16: the input / output planes are binary16 (intermediate states of one dw_step_n run, which
-// live in the same two plane buffers; a quantised state is exact in binary16).
+// Two steps (luminosities L1 then L2) in one launch on wide grids, no agent update in between.  The buffer
+// that held the input now holds the state TWO steps back, so the retained "previous state" is not valid
+// afterwards; dw_step_n always ends with an ordinary single step.
 static int launch_forward_fused2(dw_handle* h, double L1, double L2, unsigned int* pstats = nullptr,
-                                 float thr_hi = 0.f, bool in16 = false, bool out16 = false) {
+                                 float thr_hi = 0.f) {
     const dw_params& p = h->prm;
     const int in = h->cur, out = 1 - h->cur;
     PhysF32 P1, P2;
@@ -501,55 +538,38 @@ static int launch_forward_fused2(dw_handle* h, double L1, double L2, unsigned in
     const dim3 grid((unsigned)g.chunk * 8u);
     const bool rot = p.width == 256, pack = p.width < 256;
     if (p.precision == DW_PRECISION_EXACT) {
-        const FusedExactArgs A{h->L32[in], h->D32[in], h->L32[out], h->D32[out], g, P1, lum_part(P2), zero_me, zero_n,
+        const FusedExactArgs A{h->L16[in], h->D16[in], h->L16[out], h->D16[out], g, P1, lum_part(P2), zero_me, zero_n,
                                pstats, thr_hi, make_f64(p, L1), L1, L2};
-#define DW_FX(R, P, S, TI, TO) \
-    hipLaunchKernelGGL((step_stream_fused2_exact<R, P, S, TI, TO>), grid, dim3(256), 0, h->stream, A)
-#define DW_FX_FMT(R, P, S)                                                  \
-    do {                                                                    \
-        if (!in16 && !out16) DW_FX(R, P, S, float, float);                  \
-        else if (!in16) DW_FX(R, P, S, float, _Float16);                    \
-        else if (out16) DW_FX(R, P, S, _Float16, _Float16);                 \
-        else DW_FX(R, P, S, _Float16, float);                               \
-    } while (0)
+#define DW_FX(R, P, S) hipLaunchKernelGGL((step_stream_fused2_exact<R, P, S>), grid, dim3(256), 0, h->stream, A)
         if (pstats) {
-            if (pack) DW_FX_FMT(true, true, true); else if (rot) DW_FX_FMT(true, false, true); else DW_FX_FMT(false, false, true);
+            if (pack) DW_FX(true, true, true); else if (rot) DW_FX(true, false, true); else DW_FX(false, false, true);
         } else {
-            if (pack) DW_FX_FMT(true, true, false); else if (rot) DW_FX_FMT(true, false, false); else DW_FX_FMT(false, false, false);
+            if (pack) DW_FX(true, true, false); else if (rot) DW_FX(true, false, false); else DW_FX(false, false, false);
         }
-#undef DW_FX_FMT
 #undef DW_FX
     } else {
-#define DW_FF(R, P, S, TI, TO)                                                                                     \
-    hipLaunchKernelGGL((step_stream_fused2<R, P, S, TI, TO>), grid, dim3(256), 0, h->stream, h->L32[in], h->D32[in], \
-                       h->L32[out], h->D32[out], g, P1, P2, zero_me, zero_n, pstats, thr_hi)
-#define DW_FF_FMT(R, P, S)                                                  \
-    do {                                                                    \
-        if (!in16 && !out16) DW_FF(R, P, S, float, float);                  \
-        else if (!in16) DW_FF(R, P, S, float, _Float16);                    \
-        else if (out16) DW_FF(R, P, S, _Float16, _Float16);                 \
-        else DW_FF(R, P, S, _Float16, float);                               \
-    } while (0)
+#define DW_FF(R, P, S)                                                                                           \
+    hipLaunchKernelGGL((step_stream_fused2<R, P, S>), grid, dim3(256), 0, h->stream, h->L16[in], h->D16[in],      \
+                       h->L16[out], h->D16[out], g, P1, P2, zero_me, zero_n, pstats, thr_hi)
         if (pstats) {
-            if (pack) DW_FF_FMT(true, true, true); else if (rot) DW_FF_FMT(true, false, true); else DW_FF_FMT(false, false, true);
+            if (pack) DW_FF(true, true, true); else if (rot) DW_FF(true, false, true); else DW_FF(false, false, true);
         } else {
-            if (pack) DW_FF_FMT(true, true, false); else if (rot) DW_FF_FMT(true, false, false); else DW_FF_FMT(false, false, false);
+            if (pack) DW_FF(true, true, false); else if (rot) DW_FF(true, false, false); else DW_FF(false, false, false);
         }
-#undef DW_FF_FMT
 #undef DW_FF
     }
     HIPCHK(hipGetLastError());
     h->cur = out;
     h->sp = 1 - h->sp;            // the kernel cleared the old buffer; the (untouched, zero) other one is "current"
-    h->f64 = F64_NONE;
-    h->cur_quantised = true;
+    h->unq = OWN_NONE;
     h->stepped = false;
     h->L_last = L2;
+    release_unquantised(h);
     return DW_OK;
 }
 
 static int launch_agents(dw_handle* h, const int* d_action, int act_b, int act_n, bool standalone = false,
-                         bool f16 = false, double* d_reward = nullptr, unsigned char* d_done = nullptr) {
+                         double* d_reward = nullptr, unsigned char* d_done = nullptr) {
     const dw_params& p = h->prm;
     if (p.n_agents == 0) return DW_OK;
     NEED(h->have_state, DW_ESTATE, "no state uploaded");
@@ -558,18 +578,16 @@ static int launch_agents(dw_handle* h, const int* d_action, int act_b, int act_n
          "collision_mode=1: call dw_update_agents, apply the collision pass (it consumes the caller's RNG) to the "
          "downloaded agent states, upload them, then dw_step without actions");
     const int blocks = (p.batch + 63) / 64;
-    if (f16)                                       // binary16 planes between the step pairs of an episode run
-        hipLaunchKernelGGL(agents_update<_Float16>, dim3(blocks), dim3(64), 0, h->stream,
-                           reinterpret_cast<_Float16*>(h->L32[h->cur]), reinterpret_cast<_Float16*>(h->D32[h->cur]),
-                           (double*)nullptr, (double*)nullptr, h->idx, h->st, d_action, act_b, act_n,
-                           p.batch, p.n_agents, p.height, p.width, p.agent_gamma, p.collision_mode == 0 ? 1 : 0,
-                           d_reward, d_done);
-    else
-        hipLaunchKernelGGL(agents_update<float>, dim3(blocks), dim3(64), 0, h->stream, h->L32[h->cur],
-                           h->D32[h->cur], h->f64 == F64_CUR ? h->L64 : nullptr,
-                           h->f64 == F64_CUR ? h->D64 : nullptr, h->idx, h->st, d_action, act_b, act_n,
-                           p.batch, p.n_agents, p.height, p.width, p.agent_gamma, p.collision_mode == 0 ? 1 : 0,
-                           d_reward, d_done);
+#define DW_AG(T, PL, PD)                                                                                          \
+    hipLaunchKernelGGL(agents_update<T>, dim3(blocks), dim3(64), 0, h->stream, PL, PD, h->idx, h->st, d_action,    \
+                       act_b, act_n, p.batch, p.n_agents, p.height, p.width, p.agent_gamma,                        \
+                       p.collision_mode == 0 ? 1 : 0, d_reward, d_done)
+    if (h->unq == OWN_CUR) {                       // grazing on the un-quantised state, in its own format
+        if (h->unq_kind == UNQ_F64) DW_AG(double, h->L64, h->D64); else DW_AG(float, h->U32L, h->U32D);
+    } else {
+        DW_AG(plane_t, h->L16[h->cur], h->D16[h->cur]);
+    }
+#undef DW_AG
     HIPCHK(hipGetLastError());
     return DW_OK;
 }
@@ -659,8 +677,8 @@ int dw_create(const dw_params* p, dw_handle** out) {
     TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     h->own_stream = true;
     for (int i = 0; i < 2; ++i) {
-        TRY(hipMalloc(&h->L32[i], sizeof(float) * h->cells));
-        TRY(hipMalloc(&h->D32[i], sizeof(float) * h->cells));
+        TRY(hipMalloc(&h->L16[i], sizeof(plane_t) * h->cells));
+        TRY(hipMalloc(&h->D16[i], sizeof(plane_t) * h->cells));
     }
     const size_t bn = (size_t)p->batch * (p->n_agents > 0 ? p->n_agents : 1);
     TRY(hipMalloc(&h->idx, sizeof(int) * bn * 2));
@@ -684,8 +702,11 @@ int dw_create(const dw_params* p, dw_handle** out) {
     TRY(hipMemsetAsync(h->done_at, 0, sizeof(int) * p->batch, h->stream));
     TRY(hipMemsetAsync(h->agents_done_at, 0, sizeof(int) * bn, h->stream));
     TRY(hipMemsetAsync(h->n_alive, 0, sizeof(int), h->stream));
+    TRY(hipMalloc(&h->side_stats, sizeof(StatsDev) * (p->batch + 1)));
     TRY(hipEventCreate(&h->ev0));
     TRY(hipEventCreate(&h->ev1));
+    TRY(hipEventCreate(&h->evf0));
+    TRY(hipEventCreate(&h->evf1));
 #undef TRY
     select_kernel(h);
     *out = h;
@@ -696,8 +717,9 @@ int dw_destroy(dw_handle* h) {
     if (!h) return DW_OK;
     (void)hipSetDevice(h->prm.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    for (int i = 0; i < 2; ++i) { (void)hipFree(h->L32[i]); (void)hipFree(h->D32[i]); }
+    for (int i = 0; i < 2; ++i) { (void)hipFree(h->L16[i]); (void)hipFree(h->D16[i]); }
     (void)hipFree(h->L64); (void)hipFree(h->D64);
+    (void)hipFree(h->U32L); (void)hipFree(h->U32D); (void)hipFree(h->side_stats);
     (void)hipFree(h->idx); (void)hipFree(h->st); (void)hipFree(h->action); (void)hipFree(h->action_tmp);
     (void)hipFree(h->reward_d); (void)hipFree(h->done_d);
     if (h->pinned) (void)hipHostFree(h->pinned);
@@ -708,6 +730,8 @@ int dw_destroy(dw_handle* h) {
     (void)hipFree(h->stats2[0]); (void)hipFree(h->stats2[1]); (void)hipFree(h->scratch); (void)hipFree(h->ep_buf); (void)hipFree(h->fixq); (void)hipFree(h->redo_tiles);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->evf0) (void)hipEventDestroy(h->evf0);
+    if (h->evf1) (void)hipEventDestroy(h->evf1);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return DW_OK;
@@ -734,12 +758,20 @@ int dw_get_params(const dw_handle* h, dw_params* out) {
 
 // ---- state in / out ---------------------------------------------------------------------------
 
-static int refresh_stats_f32(dw_handle* h) {
+// reductions of the current state, whatever its format (after uploads / init, so that dw_reduce is always valid)
+static int refresh_stats(dw_handle* h) {
     const dw_params& p = h->prm;
     for (int i = 0; i < 2; ++i) HIPCHK(hipMemsetAsync(h->stats2[i], 0, h->stats_bytes, h->stream));
     const dim3 g((unsigned)((p.height * p.width + kStatsChunk - 1) / kStatsChunk), (unsigned)p.batch);
-    hipLaunchKernelGGL((stats_only<float>), g, dim3(256), 0, h->stream, h->L32[h->cur], h->D32[h->cur],
-                       p.height, p.width, h->stats2[h->sp]);
+    if (h->unq != OWN_CUR)
+        hipLaunchKernelGGL((stats_only<plane_t>), g, dim3(256), 0, h->stream, h->L16[h->cur], h->D16[h->cur], p.height,
+                           p.width, h->stats2[h->sp]);
+    else if (h->unq_kind == UNQ_F64)
+        hipLaunchKernelGGL((stats_only<double>), g, dim3(256), 0, h->stream, h->L64, h->D64, p.height, p.width,
+                           h->stats2[h->sp]);
+    else
+        hipLaunchKernelGGL((stats_only<float>), g, dim3(256), 0, h->stream, h->U32L, h->U32D, p.height, p.width,
+                           h->stats2[h->sp]);
     HIPCHK(hipGetLastError());
     return DW_OK;
 }
@@ -753,15 +785,12 @@ int dw_upload_state_f64(dw_handle* h, const double* light, const double* dark) {
     }
     HIPCHK(hipMemcpyAsync(h->L64, light, sizeof(double) * h->cells, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->D64, dark, sizeof(double) * h->cells, hipMemcpyHostToDevice, h->stream));
-    const unsigned blocks = (unsigned)((h->cells + 255) / 256);
-    hipLaunchKernelGGL(f64_to_permille, dim3(blocks), dim3(256), 0, h->stream, h->L64, h->L32[h->cur], h->cells);
-    hipLaunchKernelGGL(f64_to_permille, dim3(blocks), dim3(256), 0, h->stream, h->D64, h->D32[h->cur], h->cells);
-    HIPCHK(hipGetLastError());
-    h->f64 = F64_CUR;
+    h->unq_kind = UNQ_F64;
+    h->unq = OWN_CUR;
     h->have_state = true;
-    h->cur_quantised = false;
     h->stepped = false;
-    int rc = refresh_stats_f32(h);
+    h->snap_valid = false;                      // a snapshot's previous state may have lived in these buffers
+    int rc = refresh_stats(h);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(h->stream));   // host buffers may be reused by the caller
     return DW_OK;
@@ -770,20 +799,34 @@ int dw_upload_state_f64(dw_handle* h, const double* light, const double* dark) {
 int dw_upload_state_f32(dw_handle* h, const float* light, const float* dark, int quantised) {
     NEED(h && light && dark, DW_EINVAL, "null argument");
     HIPCHK(hipSetDevice(h->prm.device));
-    const int other = 1 - h->cur;   // stage natural-unit floats in the other buffer, convert in place
-    HIPCHK(hipMemcpyAsync(h->L32[other], light, sizeof(float) * h->cells, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->D32[other], dark, sizeof(float) * h->cells, hipMemcpyHostToDevice, h->stream));
     const unsigned blocks = (unsigned)((h->cells + 255) / 256);
-    hipLaunchKernelGGL(f32nat_to_permille, dim3(blocks), dim3(256), 0, h->stream, h->L32[other], h->L32[h->cur],
-                       h->cells, quantised);
-    hipLaunchKernelGGL(f32nat_to_permille, dim3(blocks), dim3(256), 0, h->stream, h->D32[other], h->D32[h->cur],
-                       h->cells, quantised);
-    HIPCHK(hipGetLastError());
-    h->f64 = F64_NONE;
+    if (quantised) {
+        // natural-unit floats staged in scratch, rounded to the per-mille integers of the canonical planes
+        int rc = ensure_scratch(h, sizeof(float) * 2 * h->cells);
+        if (rc) return rc;
+        float* sL = reinterpret_cast<float*>(h->scratch);
+        float* sD = sL + h->cells;
+        HIPCHK(hipMemcpyAsync(sL, light, sizeof(float) * h->cells, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(sD, dark, sizeof(float) * h->cells, hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(f32nat_to_plane, dim3(blocks), dim3(256), 0, h->stream, sL, h->L16[h->cur], h->cells);
+        hipLaunchKernelGGL(f32nat_to_plane, dim3(blocks), dim3(256), 0, h->stream, sD, h->D16[h->cur], h->cells);
+        HIPCHK(hipGetLastError());
+        h->unq = OWN_NONE;
+    } else {
+        int rc = ensure_u32(h);
+        if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(h->U32L, light, sizeof(float) * h->cells, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->U32D, dark, sizeof(float) * h->cells, hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(f32nat_to_permille, dim3(blocks), dim3(256), 0, h->stream, h->U32L, h->U32L, h->cells);
+        hipLaunchKernelGGL(f32nat_to_permille, dim3(blocks), dim3(256), 0, h->stream, h->U32D, h->U32D, h->cells);
+        HIPCHK(hipGetLastError());
+        h->unq_kind = UNQ_F32;
+        h->unq = OWN_CUR;
+    }
     h->have_state = true;
-    h->cur_quantised = quantised != 0;
     h->stepped = false;
-    int rc = refresh_stats_f32(h);
+    h->snap_valid = false;
+    int rc = refresh_stats(h);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(h->stream));
     return DW_OK;
@@ -828,8 +871,10 @@ int dw_init_random(dw_handle* h, uint64_t seed) {
     NEED(h, DW_EINVAL, "null handle");
     const dw_params& p = h->prm;
     HIPCHK(hipSetDevice(p.device));
+    int rc = ensure_u32(h);                     // the synthetic initial state is un-quantised like the reference's
+    if (rc) return rc;
     const dim3 g((unsigned)((p.height * p.width + 255) / 256), (unsigned)p.batch);
-    hipLaunchKernelGGL(init_random_cells, g, dim3(256), 0, h->stream, h->L32[h->cur], h->D32[h->cur], p.height,
+    hipLaunchKernelGGL(init_random_cells, g, dim3(256), 0, h->stream, h->U32L, h->U32D, p.height,
                        p.width, (long long)p.world_offset, (unsigned long long)seed, (float)p.light_proportion,
                        (float)p.dark_proportion, (float)p.initial_al, (float)p.initial_ad);
     HIPCHK(hipGetLastError());
@@ -841,11 +886,12 @@ int dw_init_random(dw_handle* h, uint64_t seed) {
         HIPCHK(hipGetLastError());
     }
     h->have_agents = true;
-    h->f64 = F64_NONE;
+    h->unq_kind = UNQ_F32;
+    h->unq = OWN_CUR;
     h->have_state = true;
-    h->cur_quantised = false;
     h->stepped = false;
-    return refresh_stats_f32(h);
+    h->snap_valid = false;
+    return refresh_stats(h);
 }
 
 int dw_download_planes(dw_handle* h, int which, double* light, double* dark) {
@@ -855,60 +901,77 @@ int dw_download_planes(dw_handle* h, int which, double* light, double* dark) {
     NEED(which == DW_STATE_CURRENT || which == DW_STATE_PREVIOUS, DW_EINVAL, "bad state selector");
     NEED(which == DW_STATE_CURRENT || h->stepped, DW_ESTATE, "no previous state before the first step");
     const int buf = which == DW_STATE_CURRENT ? h->cur : 1 - h->cur;
-    const bool exact64 = (which == DW_STATE_CURRENT && h->f64 == F64_CUR) ||
-                         (which == DW_STATE_PREVIOUS && h->f64 == F64_PREV);
+    const bool unq = (which == DW_STATE_CURRENT && h->unq == OWN_CUR) || (which == DW_STATE_PREVIOUS && h->unq == OWN_PREV);
     const size_t bytes = sizeof(double) * h->cells;
-    if (exact64) {
+    if (unq && h->unq_kind == UNQ_F64) {
         if (light) HIPCHK(hipMemcpyAsync(light, h->L64, bytes, hipMemcpyDeviceToHost, h->stream));
         if (dark) HIPCHK(hipMemcpyAsync(dark, h->D64, bytes, hipMemcpyDeviceToHost, h->stream));
     } else {
         int rc = ensure_scratch(h, bytes);
         if (rc) return rc;
         const unsigned blocks = (unsigned)((h->cells + 255) / 256);
-        if (light) {
-            hipLaunchKernelGGL(permille_to_f64, dim3(blocks), dim3(256), 0, h->stream, h->L32[buf], h->scratch, h->cells);
-            HIPCHK(hipMemcpyAsync(light, h->scratch, bytes, hipMemcpyDeviceToHost, h->stream));
+        for (int pl = 0; pl < 2; ++pl) {
+            double* dst = pl == 0 ? light : dark;
+            if (!dst) continue;
+            if (unq)
+                hipLaunchKernelGGL((plane_to_f64<float>), dim3(blocks), dim3(256), 0, h->stream,
+                                   pl == 0 ? h->U32L : h->U32D, h->scratch, h->cells);
+            else
+                hipLaunchKernelGGL((plane_to_f64<plane_t>), dim3(blocks), dim3(256), 0, h->stream,
+                                   pl == 0 ? h->L16[buf] : h->D16[buf], h->scratch, h->cells);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(dst, h->scratch, bytes, hipMemcpyDeviceToHost, h->stream));
         }
-        if (dark) {
-            hipLaunchKernelGGL(permille_to_f64, dim3(blocks), dim3(256), 0, h->stream, h->D32[buf], h->scratch, h->cells);
-            HIPCHK(hipMemcpyAsync(dark, h->scratch, bytes, hipMemcpyDeviceToHost, h->stream));
-        }
-        HIPCHK(hipGetLastError());
     }
     HIPCHK(hipStreamSynchronize(h->stream));
     return DW_OK;
 }
+
+// The state observations and the materialised grid derive their temperature channels from: after a step the
+// PRE-step state (post = true), before any step the current one (post = false); fmt 0 binary16, 1 float32
+// per-mille, 2 float64 natural.
+struct DerivedFrom { int fmt; const void* L; const void* D; bool post; };
+static DerivedFrom derived_from(const dw_handle* h) {
+    const int cur = h->cur, prev = 1 - h->cur;
+    if (h->stepped) {
+        if (h->unq == OWN_PREV)
+            return h->unq_kind == UNQ_F64 ? DerivedFrom{2, h->L64, h->D64, true} : DerivedFrom{1, h->U32L, h->U32D, true};
+        return DerivedFrom{0, h->L16[prev], h->D16[prev], true};
+    }
+    if (h->unq == OWN_CUR)
+        return h->unq_kind == UNQ_F64 ? DerivedFrom{2, h->L64, h->D64, false} : DerivedFrom{1, h->U32L, h->U32D, false};
+    return DerivedFrom{0, h->L16[cur], h->D16[cur], false};
+}
+// K<T, POST>(pL, pD, args...) for the format / phase of `src`
+#define DW_DISPATCH_DERIVED(K, src, grid, block, ...)                                                               \
+    do {                                                                                                            \
+        if ((src).fmt == 2) {                                                                                       \
+            if ((src).post) hipLaunchKernelGGL((K<double, true>), grid, block, 0, h->stream, (const double*)(src).L, (const double*)(src).D, __VA_ARGS__); \
+            else hipLaunchKernelGGL((K<double, false>), grid, block, 0, h->stream, (const double*)(src).L, (const double*)(src).D, __VA_ARGS__); \
+        } else if ((src).fmt == 1) {                                                                                \
+            if ((src).post) hipLaunchKernelGGL((K<float, true>), grid, block, 0, h->stream, (const float*)(src).L, (const float*)(src).D, __VA_ARGS__); \
+            else hipLaunchKernelGGL((K<float, false>), grid, block, 0, h->stream, (const float*)(src).L, (const float*)(src).D, __VA_ARGS__); \
+        } else {                                                                                                    \
+            if ((src).post) hipLaunchKernelGGL((K<plane_t, true>), grid, block, 0, h->stream, (const plane_t*)(src).L, (const plane_t*)(src).D, __VA_ARGS__); \
+            else hipLaunchKernelGGL((K<plane_t, false>), grid, block, 0, h->stream, (const plane_t*)(src).L, (const plane_t*)(src).D, __VA_ARGS__); \
+        }                                                                                                           \
+    } while (0)
 
 // materialise into device scratch: grid7 and/or caches
 static int run_materialise(dw_handle* h, double L, double* d_grid7, double* d_temps, double* d_betas,
                            double* d_growth, double* d_teff) {
     const dw_params& p = h->prm;
     const dim3 g((unsigned)((p.height * p.width + 255) / 256), (unsigned)p.batch);
-    const int cur = h->cur, prev = 1 - h->cur;
-    if (h->stepped) {
-        const PhysF64 P = make_f64(p, h->L_last);
-        if (h->f64 == F64_PREV)
-            hipLaunchKernelGGL((materialise<double, true>), g, dim3(256), 0, h->stream, h->L64, h->D64, h->L32[cur],
-                               h->D32[cur], p.height, p.width, P, d_grid7, d_temps, d_betas, d_growth, d_teff);
-        else
-            hipLaunchKernelGGL((materialise<float, true>), g, dim3(256), 0, h->stream, h->L32[prev], h->D32[prev],
-                               h->L32[cur], h->D32[cur], p.height, p.width, P, d_grid7, d_temps, d_betas, d_growth,
-                               d_teff);
-        HIPCHK(hipGetLastError());
-        if (d_grid7 && p.n_agents && h->have_agents) {
-            hipLaunchKernelGGL(agents_stamp, dim3((p.batch + 63) / 64), dim3(64), 0, h->stream, d_grid7, h->idx,
-                               h->st, p.batch, p.n_agents, p.height, p.width);
-            HIPCHK(hipGetLastError());
-        }
-    } else {
-        const PhysF64 P = make_f64(p, L);
-        if (h->f64 == F64_CUR)
-            hipLaunchKernelGGL((materialise<double, false>), g, dim3(256), 0, h->stream, h->L64, h->D64, h->L32[cur],
-                               h->D32[cur], p.height, p.width, P, d_grid7, d_temps, d_betas, d_growth, d_teff);
-        else
-            hipLaunchKernelGGL((materialise<float, false>), g, dim3(256), 0, h->stream, h->L32[cur], h->D32[cur],
-                               h->L32[cur], h->D32[cur], p.height, p.width, P, d_grid7, d_temps, d_betas, d_growth,
-                               d_teff);
+    const DerivedFrom src = derived_from(h);
+    const PhysF64 P = make_f64(p, src.post ? h->L_last : L);
+    const plane_t* cL = h->L16[h->cur];            // read by the POST variants only
+    const plane_t* cD = h->D16[h->cur];
+    DW_DISPATCH_DERIVED(materialise, src, g, dim3(256), cL, cD, p.height, p.width, P, d_grid7, d_temps, d_betas, d_growth,
+                        d_teff);
+    HIPCHK(hipGetLastError());
+    if (src.post && d_grid7 && p.n_agents && h->have_agents) {
+        hipLaunchKernelGGL(agents_stamp, dim3((p.batch + 63) / 64), dim3(64), 0, h->stream, d_grid7, h->idx,
+                           h->st, p.batch, p.n_agents, p.height, p.width);
         HIPCHK(hipGetLastError());
     }
     return DW_OK;
@@ -1007,61 +1070,50 @@ int dw_step_n(dw_handle* h, int32_t nsteps, double* L_io, double dL, double min_
     NEED(nsteps >= 0, DW_EINVAL, "nsteps < 0");
     HIPCHK(hipSetDevice(h->prm.device));
     double L = *L_io;
+    auto advance = [&]() { L += dL; L = L > max_L ? max_L : L; L = L < min_L ? min_L : L; };   // ref update_L :471-473
     int s0 = 0;
+    h->fused_launches = 0;
+    if (!use_device_actions && nsteps >= 1 && h->have_state && !cur_quantised(h)) {
+        int rc = launch_forward(h, L);          // the first step reads the un-quantised state in its own format
+        if (rc) return rc;
+        advance();
+        s0 = 1;
+    }
     // Small worlds: keep the whole run of steps on the chip (worlds in LDS, one launch per 4096 steps) -
     // unless the ensemble is big enough to fill the GPU with wave-strips, where the packed fused kernel is
     // 1.5-1.8x faster (measured crossover between 2 M and 16 M cells: tools/kbench.py 512 64 / 4096 64).
     const bool big_packed = h->use_stream && h->allow_fuse && h->prm.width < 256 && h->cells >= ((size_t)1 << 23);
-    if (!use_device_actions && nsteps > 1 && h->have_state && h->prm.height * h->prm.width <= 4096 && !big_packed) {
-        if (!episode_kernel_applies(h)) {          // exact mode from an un-quantised state: one ordinary step first
-            int rc = launch_forward(h, L);
+    if (!use_device_actions && nsteps - s0 > 1 && h->have_state && h->prm.height * h->prm.width <= 4096 && !big_packed &&
+        episode_kernel_applies(h)) {
+        std::vector<double> Ls;
+        while (s0 < nsteps) {
+            const int k = nsteps - s0 < 4096 ? nsteps - s0 : 4096;
+            Ls.resize(k);
+            for (int i = 0; i < k; ++i) { Ls[i] = L; advance(); }
+            int rc = run_episode_impl(h, k, Ls.data(), kPolicySkipAgents, nullptr, nullptr, 5, nullptr, nullptr);
             if (rc) return rc;
-            L += dL; L = L > max_L ? max_L : L; L = L < min_L ? min_L : L;
-            s0 = 1;
+            s0 += k;
         }
-        if (episode_kernel_applies(h)) {
-            std::vector<double> Ls;
-            while (s0 < nsteps) {
-                const int k = nsteps - s0 < 4096 ? nsteps - s0 : 4096;
-                Ls.resize(k);
-                for (int i = 0; i < k; ++i) {
-                    Ls[i] = L;
-                    L += dL; L = L > max_L ? max_L : L; L = L < min_L ? min_L : L;
-                }
-                int rc = run_episode_impl(h, k, Ls.data(), kPolicySkipAgents, nullptr, nullptr, 5, nullptr, nullptr);
-                if (rc) return rc;
-                s0 += k;
-            }
-            *L_io = L;
-            return DW_OK;
-        }
+        *L_io = L;
+        return DW_OK;
     }
     if (!use_device_actions && h->allow_fuse && h->use_stream && h->have_state &&
-        (h->prm.precision == DW_PRECISION_FAST || h->prm.precision == DW_PRECISION_EXACT)) {
-        if (h->prm.precision == DW_PRECISION_EXACT && !h->cur_quantised && nsteps - s0 >= 1) {
-            int rc = launch_forward(h, L);       // exact mode: first step from an un-quantised state in float64
-            if (rc) return rc;
-            L += dL; L = L > max_L ? max_L : L; L = L < min_L ? min_L : L;
-            s0 += 1;
-        }
-        // float32-only mode on wide grids: pairs of steps share one HBM round trip; the last one or two
-        // steps are ordinary launches so that the retained previous state is the true predecessor
-        // The states BETWEEN the fused launches of this call are never seen by anything else: they are kept
-        // as binary16 planes (lossless for a quantised state), which halves the HBM traffic of the run; the
-        // first launch reads and the last one writes float32.
-        const int nfused = (nsteps - s0 - 1) / 2;
-        for (int i = 0; nsteps - s0 >= 3; ++i) {
+        (h->prm.precision == DW_PRECISION_FAST || h->prm.precision == DW_PRECISION_EXACT) && nsteps - s0 >= 3) {
+        // wide grids: pairs of steps share one HBM round trip; the last one or two steps are ordinary launches
+        // so that the retained previous state is the true predecessor.  HIP events around the run of fused
+        // launches feed dw_last_step_n_timing (the dominant kernel's duration, measured on its own stream).
+        HIPCHK(hipEventRecord(h->evf0, h->stream));
+        while (nsteps - s0 >= 3) {
             const double L1 = L;
-            L += dL; L = L > max_L ? max_L : L; L = L < min_L ? min_L : L;
+            advance();
             const double L2 = L;
-            L += dL; L = L > max_L ? max_L : L; L = L < min_L ? min_L : L;
-            int rc = launch_forward_fused2(h, L1, L2, nullptr, 0.f, h->allow_f16 && i > 0, h->allow_f16 && i < nfused - 1);
-            if (rc) {
-                if (h->allow_f16 && i > 0) h->have_state = false;   // the planes hold a binary16 intermediate
-                return rc;
-            }
+            advance();
+            int rc = launch_forward_fused2(h, L1, L2);
+            if (rc) return rc;
             s0 += 2;
+            h->fused_launches += 1;
         }
+        HIPCHK(hipEventRecord(h->evf1, h->stream));
     }
     for (int s = s0; s < nsteps; ++s) {
         int rc;
@@ -1071,11 +1123,22 @@ int dw_step_n(dw_handle* h, int32_t nsteps, double* L_io, double dL, double min_
         }
         rc = launch_forward(h, L);
         if (rc) return rc;
-        L += dL;                                           // ref update_L :471-473
-        L = L > max_L ? max_L : L;
-        L = L < min_L ? min_L : L;
+        advance();
     }
     *L_io = L;
+    return DW_OK;
+}
+
+int dw_last_step_n_timing(dw_handle* h, float* fused_ms, int32_t* fused_launches, int32_t* plane_elem_bytes) {
+    NEED(h && fused_ms && fused_launches && plane_elem_bytes, DW_EINVAL, "null argument");
+    HIPCHK(hipSetDevice(h->prm.device));
+    *fused_ms = 0.f;
+    *fused_launches = h->fused_launches;
+    *plane_elem_bytes = (int32_t)sizeof(plane_t);
+    if (h->fused_launches > 0) {
+        HIPCHK(hipEventSynchronize(h->evf1));
+        HIPCHK(hipEventElapsedTime(fused_ms, h->evf0, h->evf1));
+    }
     return DW_OK;
 }
 
@@ -1085,8 +1148,8 @@ int dw_forward_f64(dw_handle* h, const double* light, const double* dark, double
     const dw_params& p = h->prm;
     HIPCHK(hipSetDevice(p.device));
     const size_t n = h->cells;
-    // scratch layout: [in light n][in dark n][grid7 7n][caches 9n] doubles, [new light n][new dark n] floats
-    int rc = ensure_scratch(h, sizeof(double) * 18 * n + sizeof(float) * 2 * n);
+    // scratch layout: [in light n][in dark n][grid7 7n][caches 9n] doubles, [new light n][new dark n] binary16
+    int rc = ensure_scratch(h, sizeof(double) * 18 * n + sizeof(plane_t) * 2 * n + 16);
     if (rc) return rc;
     double* dL = h->scratch;
     double* dD = dL + n;
@@ -1095,17 +1158,22 @@ int dw_forward_f64(dw_handle* h, const double* light, const double* dark, double
     double* d_b = d_t + 3 * n;
     double* d_g = d_b + 3 * n;
     double* d_e = d_g + 2 * n;
-    float* nL = reinterpret_cast<float*>(d_e + n);
-    float* nD = nL + n;
+    plane_t* nL = reinterpret_cast<plane_t*>(d_e + n);
+    plane_t* nD = nL + n;
+    // the reductions of this side computation must not disturb the handle's per-world stats
+    StatsDev* tmp_stats = h->side_stats;
+    HIPCHK(hipMemsetAsync(tmp_stats, 0, sizeof(StatsDev) * (p.batch + 1), h->stream));
     HIPCHK(hipMemcpyAsync(dL, light, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(dD, dark, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
+    {
+        const hipError_t e2 = hipMemcpyAsync(dD, dark, sizeof(double) * n, hipMemcpyHostToDevice, h->stream);
+        if (e2 != hipSuccess) {
+            (void)hipStreamSynchronize(h->stream);      // the first copy may still be reading `light`
+            return fail(DW_EHIP, "dw_forward_f64: %s", hipGetErrorString(e2));
+        }
+    }
     const PhysF32 P = derive_f32(p, L);
     const PhysF64 P64 = make_f64(p, L);
     const dim3 g((unsigned)((p.height * p.width + 255) / 256), (unsigned)p.batch);
-    // the reductions of this side computation must not disturb the handle's per-world stats
-    StatsDev* tmp_stats = nullptr;
-    HIPCHK(hipMalloc(&tmp_stats, sizeof(StatsDev) * (p.batch + 1)));
-    HIPCHK(hipMemsetAsync(tmp_stats, 0, sizeof(StatsDev) * (p.batch + 1), h->stream));
     unsigned long long* tmp_fix = &tmp_stats[p.batch].sum_l;
     hipLaunchKernelGGL((step_generic<double, 2>), g, dim3(256), 0, h->stream, dL, dD, nL, nD, p.height, p.width, P,
                        P64, tmp_stats, tmp_fix, (unsigned long long*)nullptr, 0);
@@ -1124,8 +1192,9 @@ int dw_forward_f64(dw_handle* h, const double* light, const double* dark, double
     if (le == hipSuccess && growth) le = hipMemcpyAsync(growth, d_g, sizeof(double) * 2 * n, hipMemcpyDeviceToHost, h->stream);
     if (le == hipSuccess && temp_effective)
         le = hipMemcpyAsync(temp_effective, d_e, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream);
-    if (le == hipSuccess) le = hipStreamSynchronize(h->stream);
-    (void)hipFree(tmp_stats);
+    // the caller's host buffers are the targets of copies in flight: never return before the stream is idle
+    const hipError_t se = hipStreamSynchronize(h->stream);
+    if (le == hipSuccess) le = se;
     if (le != hipSuccess) return fail(DW_EHIP, "dw_forward_f64: %s", hipGetErrorString(le));
     return DW_OK;
 }
@@ -1138,33 +1207,8 @@ int dw_get_obs(dw_handle* h, double L_init, double* obs) {
     if (bn == 0) return DW_OK;
     NEED(obs, DW_EINVAL, "null obs");
     NEED(h->have_state && h->have_agents, DW_ESTATE, "no state / agents");
-    int rc = ensure_scratch(h, sizeof(double) * bn * 63);
+    int rc = observe_into_scratch(h, L_init, 0);
     if (rc) return rc;
-    const int threads = (int)(bn * 9);
-    const dim3 g((threads + 127) / 128);
-    const int cur = h->cur, prev = 1 - h->cur;
-    if (h->stepped) {
-        const PhysF64 P = make_f64(p, h->L_last);
-        if (h->f64 == F64_PREV)
-            hipLaunchKernelGGL((observe<double, true>), g, dim3(128), 0, h->stream, h->L64, h->D64, h->L32[cur],
-                               h->D32[cur], h->idx, h->st, p.batch, p.n_agents, p.height, p.width, P, p.obs_mask,
-                               h->scratch);
-        else
-            hipLaunchKernelGGL((observe<float, true>), g, dim3(128), 0, h->stream, h->L32[prev], h->D32[prev],
-                               h->L32[cur], h->D32[cur], h->idx, h->st, p.batch, p.n_agents, p.height, p.width, P,
-                               p.obs_mask, h->scratch);
-    } else {
-        const PhysF64 P = make_f64(p, L_init);
-        if (h->f64 == F64_CUR)
-            hipLaunchKernelGGL((observe<double, false>), g, dim3(128), 0, h->stream, h->L64, h->D64, h->L32[cur],
-                               h->D32[cur], h->idx, h->st, p.batch, p.n_agents, p.height, p.width, P, p.obs_mask,
-                               h->scratch);
-        else
-            hipLaunchKernelGGL((observe<float, false>), g, dim3(128), 0, h->stream, h->L32[cur], h->D32[cur],
-                               h->L32[cur], h->D32[cur], h->idx, h->st, p.batch, p.n_agents, p.height, p.width, P,
-                               p.obs_mask, h->scratch);
-    }
-    HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(obs, h->scratch, sizeof(double) * bn * 63, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return DW_OK;
@@ -1253,6 +1297,22 @@ int dw_reduce(dw_handle* h, dw_world_stats* per_world) {
     return DW_OK;
 }
 
+// Greedy / anti-greedy choice of every agent from the CURRENT covers (ref Greedy.__call__, agents/greedy.py:18-30)
+// into h->action; agent_mode / codes as in policy_greedy (dw_agents.hpp).
+static int launch_policy_greedy(dw_handle* h, int argmin, const int* agent_mode, int codes) {
+    const dw_params& p = h->prm;
+    const int bn = p.batch * p.n_agents;
+    const dim3 g((unsigned)((bn + 255) / 256));
+    if (h->unq == OWN_CUR && h->unq_kind == UNQ_F32)
+        hipLaunchKernelGGL(policy_greedy<float>, g, dim3(256), 0, h->stream, h->U32L, h->U32D, h->idx, p.batch, p.n_agents,
+                           p.height, p.width, p.obs_mask, argmin, agent_mode, h->action, codes);
+    else
+        hipLaunchKernelGGL(policy_greedy<plane_t>, g, dim3(256), 0, h->stream, h->L16[h->cur], h->D16[h->cur], h->idx,
+                           p.batch, p.n_agents, p.height, p.width, p.obs_mask, argmin, agent_mode, h->action, codes);
+    HIPCHK(hipGetLastError());
+    return DW_OK;
+}
+
 int dw_policy_greedy(dw_handle* h, int mode) {
     NEED(h, DW_EINVAL, "null handle");
     const dw_params& p = h->prm;
@@ -1261,13 +1321,9 @@ int dw_policy_greedy(dw_handle* h, int mode) {
     if (bn == 0) return DW_OK;
     NEED(h->have_state && h->have_agents, DW_ESTATE, "no state / agents");
     NEED(mode == DW_POLICY_ARGMAX || mode == DW_POLICY_ARGMIN, DW_EINVAL, "bad policy mode");
-    NEED(h->cur_quantised || h->f64 != F64_CUR, DW_ESTATE,
+    NEED(cur_quantised(h) || h->unq_kind != UNQ_F64, DW_ESTATE,
          "device policy on an exact float64 initial state is not supported; compute the action on the host");
-    hipLaunchKernelGGL(policy_greedy<float>, dim3((bn + 255) / 256), dim3(256), 0, h->stream, h->L32[h->cur], h->D32[h->cur],
-                       h->idx, p.batch, p.n_agents, p.height, p.width, p.obs_mask, mode == DW_POLICY_ARGMIN ? 1 : 0,
-                       (const int*)nullptr, h->action);
-    HIPCHK(hipGetLastError());
-    return DW_OK;
+    return launch_policy_greedy(h, mode == DW_POLICY_ARGMIN ? 1 : 0, nullptr, 0);
 }
 
 int dw_policy_per_agent(dw_handle* h, const int32_t* agent_mode) {
@@ -1277,7 +1333,7 @@ int dw_policy_per_agent(dw_handle* h, const int32_t* agent_mode) {
     const int bn = p.batch * p.n_agents;
     if (bn == 0) return DW_OK;
     NEED(h->have_state && h->have_agents, DW_ESTATE, "no state / agents");
-    NEED(h->cur_quantised || h->f64 != F64_CUR, DW_ESTATE,
+    NEED(cur_quantised(h) || h->unq_kind != UNQ_F64, DW_ESTATE,
          "device policy on an exact float64 initial state is not supported; compute the action on the host");
     for (int n = 0; n < p.n_agents; ++n)
         NEED(agent_mode[n] == DW_POLICY_ARGMAX || agent_mode[n] == DW_POLICY_ARGMIN || agent_mode[n] == DW_POLICY_TABLE,
@@ -1286,11 +1342,9 @@ int dw_policy_per_agent(dw_handle* h, const int32_t* agent_mode) {
     std::vector<int> m(p.n_agents);
     for (int n = 0; n < p.n_agents; ++n) m[n] = agent_mode[n] == DW_POLICY_TABLE ? 2 : agent_mode[n];
     HIPCHK(hipMemcpyAsync(h->action_tmp, m.data(), sizeof(int) * p.n_agents, hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(policy_greedy<float>, dim3((bn + 255) / 256), dim3(256), 0, h->stream, h->L32[h->cur], h->D32[h->cur],
-                       h->idx, p.batch, p.n_agents, p.height, p.width, p.obs_mask, 0, h->action_tmp, h->action);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(h->stream));      // `m` is a local host buffer
-    return DW_OK;
+    const int prc = launch_policy_greedy(h, 0, h->action_tmp, 0);
+    HIPCHK(hipStreamSynchronize(h->stream));      // `m` is a local host buffer: also on the error path
+    return prc;
 }
 
 // fills h->scratch with the [B][N][63] observations of the current state (device side of dw_get_obs)
@@ -1304,28 +1358,12 @@ static int observe_into_scratch(dw_handle* h, double L_init, size_t extra_bytes,
     unsigned char* d_done = reward_tail ? reinterpret_cast<unsigned char*>(h->scratch + bn * 64) : nullptr;
     const int threads = (int)(bn * 9);
     const dim3 g((threads + 127) / 128);
-    const int cur = h->cur, prev = 1 - h->cur;
-    if (h->stepped) {
-        const PhysF64 P = make_f64(p, h->L_last);
-        if (h->f64 == F64_PREV)
-            hipLaunchKernelGGL((observe<double, true>), g, dim3(128), 0, h->stream, h->L64, h->D64, h->L32[cur],
-                               h->D32[cur], h->idx, h->st, p.batch, p.n_agents, p.height, p.width, P, p.obs_mask,
-                               h->scratch, d_rew, d_done);
-        else
-            hipLaunchKernelGGL((observe<float, true>), g, dim3(128), 0, h->stream, h->L32[prev], h->D32[prev],
-                               h->L32[cur], h->D32[cur], h->idx, h->st, p.batch, p.n_agents, p.height, p.width, P,
-                               p.obs_mask, h->scratch, d_rew, d_done);
-    } else {
-        const PhysF64 P = make_f64(p, L_init);
-        if (h->f64 == F64_CUR)
-            hipLaunchKernelGGL((observe<double, false>), g, dim3(128), 0, h->stream, h->L64, h->D64, h->L32[cur],
-                               h->D32[cur], h->idx, h->st, p.batch, p.n_agents, p.height, p.width, P, p.obs_mask,
-                               h->scratch, d_rew, d_done);
-        else
-            hipLaunchKernelGGL((observe<float, false>), g, dim3(128), 0, h->stream, h->L32[cur], h->D32[cur],
-                               h->L32[cur], h->D32[cur], h->idx, h->st, p.batch, p.n_agents, p.height, p.width, P,
-                               p.obs_mask, h->scratch, d_rew, d_done);
-    }
+    const DerivedFrom src = derived_from(h);
+    const PhysF64 P = make_f64(p, src.post ? h->L_last : L_init);
+    const plane_t* cL = h->L16[h->cur];            // read by the POST variants only
+    const plane_t* cD = h->D16[h->cur];
+    DW_DISPATCH_DERIVED(observe, src, g, dim3(128), cL, cD, h->idx, h->st, p.batch, p.n_agents, p.height, p.width, P,
+                        p.obs_mask, h->scratch, d_rew, d_done);
     HIPCHK(hipGetLastError());
     return DW_OK;
 }
@@ -1347,13 +1385,15 @@ static int policy_mlp_impl(dw_handle* h, const double* params, int32_t n_members
     if (rc) return rc;
     double* d_w = h->scratch + bn * 63;
     int* d_m = world_member ? reinterpret_cast<int*>(d_w + 1808 * (size_t)n_members) : nullptr;
+    SyncOnExit guard(h->stream);                              // params / world_member are the caller's
     HIPCHK(hipMemcpyAsync(d_w, params, wbytes, hipMemcpyHostToDevice, h->stream));
     if (world_member) HIPCHK(hipMemcpyAsync(d_m, world_member, mbytes, hipMemcpyHostToDevice, h->stream));
     const int n = p.batch * (agent_end - agent_begin);
     hipLaunchKernelGGL(policy_mlp, dim3((n + 3) / 4), dim3(64), 0, h->stream, h->scratch, d_w, d_m, p.batch,
                        p.n_agents, agent_begin, agent_end, h->action);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(h->stream));       // params / world_member are caller-owned host buffers
+    HIPCHK(hipStreamSynchronize(h->stream));
+    guard.disarm();
     return DW_OK;
 }
 
@@ -1405,6 +1445,7 @@ int dw_run_episode_mlp(dw_handle* h, int32_t nsteps, const double* L_schedule, c
     const int* d_mb = member_b ? reinterpret_cast<const int*>(h->ep_buf + o_mb) : nullptr;
     double* d_r = reinterpret_cast<double*>(h->ep_buf + o_r);
     unsigned char* d_d = h->ep_buf + o_d;
+    SyncOnExit guard(h->stream);                              // params / member maps are the caller's
     HIPCHK(hipMemcpyAsync(h->ep_buf + o_w, params, wbytes, hipMemcpyHostToDevice, h->stream));
     if (member_a) HIPCHK(hipMemcpyAsync(h->ep_buf + o_ma, member_a, sizeof(int) * B, hipMemcpyHostToDevice, h->stream));
     if (member_b) HIPCHK(hipMemcpyAsync(h->ep_buf + o_mb, member_b, sizeof(int) * B, hipMemcpyHostToDevice, h->stream));
@@ -1416,7 +1457,7 @@ int dw_run_episode_mlp(dw_handle* h, int32_t nsteps, const double* L_schedule, c
         hipLaunchKernelGGL(policy_mlp, dim3((unsigned)((bn + 3) / 4)), dim3(64), 0, h->stream, h->scratch, d_w, d_ma, B, N,
                            0, N, h->action, d_mb, split);
         HIPCHK(hipGetLastError());
-        rc = launch_agents(h, h->action, B, N, false, false, d_r + t * bn, d_d + t * bn);
+        rc = launch_agents(h, h->action, B, N, false, d_r + t * bn, d_d + t * bn);
         if (rc) return rc;
         rc = launch_forward(h, L_schedule[t]);
         if (rc) return rc;
@@ -1424,6 +1465,7 @@ int dw_run_episode_mlp(dw_handle* h, int32_t nsteps, const double* L_schedule, c
     if (reward) HIPCHK(hipMemcpyAsync(reward, d_r, sizeof(double) * K * bn, hipMemcpyDeviceToHost, h->stream));
     if (done) HIPCHK(hipMemcpyAsync(done, d_d, K * bn, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    guard.disarm();
     return DW_OK;
 }
 
@@ -1474,7 +1516,7 @@ int dw_run_episode(dw_handle* h, int32_t nsteps, const double* L_schedule, int p
 static bool episode_kernel_applies(const dw_handle* h) {
     const dw_params& p = h->prm;
     return p.height * p.width <= 4096 && p.precision != DW_PRECISION_F64 && p.collision_mode == 0 &&
-           (p.precision != DW_PRECISION_EXACT || h->cur_quantised) && !std::getenv("DW_NO_EPISODE_KERNEL");
+           cur_quantised(h) && !std::getenv("DW_NO_EPISODE_KERNEL");
 }
 
 // dw_run_episode for worlds that do not fit LDS: the same K steps as K x (policy, dw_step) issued
@@ -1490,6 +1532,7 @@ static int run_episode_stepwise(dw_handle* h, int32_t nsteps, const double* L_sc
     const size_t o_tab = 0, o_wa = up(o_tab + K * bn), o_ok = up(o_wa + K * B), o_code = up(o_ok + K * bn);
     const size_t o_ps = up(o_code + bn), total = up(o_ps + sizeof(unsigned int) * 2 * B) + 256;
     if (int erc = ensure_ep_buf(h, total)) return erc;
+    SyncOnExit guard(h->stream);                              // `table` is the caller's
     if (table && bn) HIPCHK(hipMemcpyAsync(h->ep_buf + o_tab, table, K * bn, hipMemcpyHostToDevice, h->stream));
     const int nflag = B > (int)bn ? B : (int)bn;
     // Step pairs on wide grids (dw_agents_fused.hpp): policy_t, graze_t, ONE fused launch for forward_t and
@@ -1502,48 +1545,31 @@ static int run_episode_stepwise(dw_handle* h, int32_t nsteps, const double* L_sc
     // With per-step world flags the fused launch also reduces what the flags of both steps need (STATS
     // variants: exact step-1 maximum, count of certain step-2 values above the threshold).
     unsigned int* pstats = world_alive ? reinterpret_cast<unsigned int*>(h->ep_buf + o_ps) : nullptr;
-    // Between consecutive step pairs of this call the planes are binary16 (as in dw_step_n: lossless for the
-    // quantised state, half the traffic of the fused launches); `cur16` says what the current buffer holds.
-    // The pair before an ordinary step writes float32, so the call always ends on float32 planes.
-    bool cur16 = false;
-    auto greedy = [&](int argmin, int codes) {
-        const dim3 g((unsigned)((bn + 255) / 256));
-        if (cur16)
-            hipLaunchKernelGGL(policy_greedy<_Float16>, g, dim3(256), 0, h->stream,
-                               reinterpret_cast<const _Float16*>(h->L32[h->cur]),
-                               reinterpret_cast<const _Float16*>(h->D32[h->cur]), h->idx, B, N, p.height, p.width,
-                               p.obs_mask, argmin, (const int*)nullptr, h->action, codes);
-        else
-            hipLaunchKernelGGL(policy_greedy<float>, g, dim3(256), 0, h->stream, h->L32[h->cur], h->D32[h->cur], h->idx,
-                               B, N, p.height, p.width, p.obs_mask, argmin, (const int*)nullptr, h->action, codes);
-    };
+    auto greedy = [&](int argmin, int codes) { return launch_policy_greedy(h, argmin, nullptr, codes); };
     for (size_t t = 0; t < K; ++t) {
-        const bool pair = may_pair && h->cur_quantised && K - t >= 3;
+        const bool pair = may_pair && cur_quantised(h) && K - t >= 3;
         if (bn && policy_mode != kPolicySkipAgents) {
             const bool from_table = policy_mode == DW_POLICY_TABLE || (use_table && use_table[t]);
             if (from_table) {
                 hipLaunchKernelGGL(actions_from_table, dim3((unsigned)((bn + 255) / 256)), dim3(256), 0, h->stream,
                                    reinterpret_cast<const signed char*>(h->ep_buf + o_tab + t * bn), (int)bn, h->action);
-                greedy(0, 1);                                               // codes -1 / -2: greedy / anti-greedy
+                if (int prc = greedy(0, 1)) return prc;                      // codes -1 / -2: greedy / anti-greedy
             } else if (policy_mode == DW_POLICY_ZEROS) {
                 HIPCHK(hipMemsetAsync(h->action, 0, sizeof(int) * bn, h->stream));
             } else {
-                greedy(policy_mode == DW_POLICY_ARGMIN ? 1 : 0, 0);
+                if (int prc = greedy(policy_mode == DW_POLICY_ARGMIN ? 1 : 0, 0)) return prc;
             }
             HIPCHK(hipGetLastError());
-            int rc = launch_agents(h, h->action, B, N, false, cur16);
-            if (rc) { if (cur16) h->have_state = false; return rc; }
+            int rc = launch_agents(h, h->action, B, N);
+            if (rc) return rc;
         }
         if (pair) {
             hipLaunchKernelGGL(agent_flags, dim3((unsigned)((bn + 255) / 256)), dim3(256), 0, h->stream, h->st, (int)bn,
                                h->ep_buf + o_ok + t * bn);
             const double L1 = L_schedule[t], L2 = L_schedule[t + 1];
             if (pstats) HIPCHK(hipMemsetAsync(pstats, 0, sizeof(unsigned int) * 2 * B, h->stream));
-            const bool in16 = cur16;
-            const bool out16 = h->allow_f16 && K - (t + 2) >= 3;           // the next two steps are a pair again
-            int rc = launch_forward_fused2(h, L1, L2, pstats, (float)threshold_k, in16, out16);
-            if (rc) { if (in16) h->have_state = false; return rc; }
-            cur16 = out16;
+            int rc = launch_forward_fused2(h, L1, L2, pstats, (float)threshold_k);
+            if (rc) return rc;
             // codes of step t+1: the caller's table slice, or one byte value for the whole ensemble
             const bool tab2 = policy_mode == DW_POLICY_TABLE || (use_table && use_table[t + 1]);
             unsigned char* codes = h->ep_buf + o_code;
@@ -1554,8 +1580,8 @@ static int run_episode_stepwise(dw_handle* h, int32_t nsteps, const double* L_sc
                 HIPCHK(hipMemsetAsync(codes, v, bn, h->stream));
             }
             LookaheadArgs A;
-            A.inL = h->L32[1 - h->cur]; A.inD = h->D32[1 - h->cur];
-            A.outL = h->L32[h->cur]; A.outD = h->D32[h->cur];
+            A.inL = h->L16[1 - h->cur]; A.inD = h->D16[1 - h->cur];
+            A.outL = h->L16[h->cur]; A.outD = h->D16[h->cur];
             A.idx = h->idx; A.st = h->st;
             A.code = reinterpret_cast<const signed char*>(codes);
             A.agent_ok = h->ep_buf + o_ok + (t + 1) * bn;
@@ -1566,22 +1592,14 @@ static int run_episode_stepwise(dw_handle* h, int32_t nsteps, const double* L_sc
             A.agent_gamma = p.agent_gamma;
             A.P1 = derive_f32(p, L1); A.P2 = derive_f32(p, L2);
             A.P64 = make_f64(p, L1); A.La = L1; A.Lb = L2;
-#define DW_LA(E, TI, TO) hipLaunchKernelGGL((agents_lookahead_patch<E, TI, TO>), dim3((unsigned)B), dim3(64), 0, h->stream, A)
-#define DW_LA_FMT(E)                                              \
-    do {                                                          \
-        if (!in16 && !out16) DW_LA(E, float, float);              \
-        else if (!in16) DW_LA(E, float, _Float16);                \
-        else if (out16) DW_LA(E, _Float16, _Float16);             \
-        else DW_LA(E, _Float16, float);                           \
-    } while (0)
-            if (p.precision == DW_PRECISION_EXACT) DW_LA_FMT(true); else DW_LA_FMT(false);
-#undef DW_LA_FMT
-#undef DW_LA
+            if (p.precision == DW_PRECISION_EXACT)
+                hipLaunchKernelGGL((agents_lookahead_patch<true>), dim3((unsigned)B), dim3(64), 0, h->stream, A);
+            else
+                hipLaunchKernelGGL((agents_lookahead_patch<false>), dim3((unsigned)B), dim3(64), 0, h->stream, A);
             HIPCHK(hipGetLastError());
             ++t;                                             // two steps done
             continue;
         }
-        NEED(!cur16, DW_EINVAL, "internal: ordinary step on binary16 planes");
         int rc = launch_forward(h, L_schedule[t]);
         if (rc) return rc;
         hipLaunchKernelGGL(episode_flags, dim3((unsigned)((nflag + 255) / 256)), dim3(256), 0, h->stream,
@@ -1591,6 +1609,7 @@ static int run_episode_stepwise(dw_handle* h, int32_t nsteps, const double* L_sc
     if (world_alive) HIPCHK(hipMemcpyAsync(world_alive, h->ep_buf + o_wa, K * B, hipMemcpyDeviceToHost, h->stream));
     if (agent_ok && bn) HIPCHK(hipMemcpyAsync(agent_ok, h->ep_buf + o_ok, K * bn, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    guard.disarm();
     return DW_OK;
 }
 
@@ -1605,8 +1624,7 @@ static int run_episode_impl(dw_handle* h, int32_t nsteps, const double* L_schedu
     const int C = p.height * p.width, N = p.n_agents, B = p.batch;
     NEED(h->have_state, DW_ESTATE, "no state uploaded");
     NEED(N == 0 || h->have_agents, DW_ESTATE, "no agents uploaded");
-    NEED(p.precision != DW_PRECISION_EXACT || h->cur_quantised, DW_ESTATE,
-         "exact mode: the current state is not quantised yet; take the first step with dw_step");
+    NEED(cur_quantised(h), DW_ESTATE, "the current state is not quantised yet; take the first step with dw_step");
     NEED(policy_mode != DW_POLICY_TABLE || table, DW_EINVAL, "DW_POLICY_TABLE needs a table");
     if (use_table && !table)
         for (int t = 0; t < nsteps; ++t) NEED(!use_table[t], DW_EINVAL, "use_table set but no table given");
@@ -1627,6 +1645,7 @@ static int run_episode_impl(dw_handle* h, int32_t nsteps, const double* L_schedu
     for (size_t t = 0; t < K; ++t) p32[t] = derive_f32(p, L_schedule[t]);
     std::vector<unsigned char> ut(K, 0);
     if (use_table) std::memcpy(ut.data(), use_table, K);
+    SyncOnExit guard(h->stream);                              // p32 / ut above and the caller's arrays
     HIPCHK(hipMemcpyAsync(h->ep_buf + o_p32, p32.data(), sizeof(PhysF32) * K, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->ep_buf + o_ls, L_schedule, sizeof(double) * K, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->ep_buf + o_ut, ut.data(), K, hipMemcpyHostToDevice, h->stream));
@@ -1635,7 +1654,7 @@ static int run_episode_impl(dw_handle* h, int32_t nsteps, const double* L_schedu
     HIPCHK(hipMemsetAsync(stats, 0, sizeof(StatsDev) * (B + 1), h->stream));
     EpisodeIO io;
     const int cur = h->cur, prev = 1 - h->cur;
-    io.L = h->L32[cur]; io.D = h->D32[cur]; io.prevL = h->L32[prev]; io.prevD = h->D32[prev];
+    io.L = h->L16[cur]; io.D = h->D16[cur]; io.prevL = h->L16[prev]; io.prevD = h->D16[prev];
     io.idx = h->idx; io.st = h->st;
     io.P32 = reinterpret_cast<const PhysF32*>(h->ep_buf + o_p32);
     io.Ls = reinterpret_cast<const double*>(h->ep_buf + o_ls);
@@ -1655,11 +1674,12 @@ static int run_episode_impl(dw_handle* h, int32_t nsteps, const double* L_schedu
     HIPCHK(hipGetLastError());
     if (world_alive) HIPCHK(hipMemcpyAsync(world_alive, h->ep_buf + o_wa, K * B, hipMemcpyDeviceToHost, h->stream));
     if (agent_ok && bn) HIPCHK(hipMemcpyAsync(agent_ok, h->ep_buf + o_ok, K * bn, hipMemcpyDeviceToHost, h->stream));
-    h->f64 = F64_NONE;
-    h->cur_quantised = true;
+    h->unq = OWN_NONE;
     h->stepped = true;
     h->L_last = L_schedule[K - 1];
-    HIPCHK(hipStreamSynchronize(h->stream));      // host vectors above go out of scope; flags are returned
+    release_unquantised(h);
+    HIPCHK(hipStreamSynchronize(h->stream));      // flags are returned
+    guard.disarm();
     return DW_OK;
 }
 
@@ -1669,39 +1689,41 @@ int dw_snapshot_save(dw_handle* h) {
     const dw_params& p = h->prm;
     HIPCHK(hipSetDevice(p.device));
     NEED(h->have_state, DW_ESTATE, "no state uploaded");
-    NEED(h->f64 != F64_CUR, DW_ESTATE, "the current state is an un-quantised float64 upload; take a step first");
+    NEED(cur_quantised(h), DW_ESTATE, "the current state is an un-quantised upload; take a step first");
     const size_t bn = (size_t)p.batch * p.n_agents;
+    const size_t pb = sizeof(plane_t) * h->cells;
     if (!h->snapL) {
-        HIPCHK(hipMalloc(&h->snapL, sizeof(float) * h->cells));
-        HIPCHK(hipMalloc(&h->snapD, sizeof(float) * h->cells));
+        HIPCHK(hipMalloc(&h->snapL, pb));
+        HIPCHK(hipMalloc(&h->snapD, pb));
         HIPCHK(hipMalloc(&h->snap_stats, h->stats_bytes));
         if (bn) {
             HIPCHK(hipMalloc(&h->snap_idx, sizeof(int) * 2 * bn));
             HIPCHK(hipMalloc(&h->snap_st, sizeof(double) * bn));
         }
     }
-    HIPCHK(hipMemcpyAsync(h->snapL, h->L32[h->cur], sizeof(float) * h->cells, hipMemcpyDeviceToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->snapD, h->D32[h->cur], sizeof(float) * h->cells, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->snapL, h->L16[h->cur], pb, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->snapD, h->D16[h->cur], pb, hipMemcpyDeviceToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->snap_stats, h->stats2[h->sp], h->stats_bytes, hipMemcpyDeviceToDevice, h->stream));
     // the previous state too: observations (temperature channels) and the temp / beta / growth caches are
-    // derived from it, so a replay from the snapshot must see the same one
+    // derived from it, so a replay from the snapshot must see the same one.  An un-quantised previous state
+    // (the step after an upload) stays where it is: its buffers are not reused before the next upload, which
+    // invalidates the snapshot.
     h->snap_stepped = h->stepped;
     h->snap_L_last = h->L_last;
-    h->snap_f64 = h->f64;
-    if (h->stepped && h->f64 != F64_PREV) {
+    h->snap_unq = h->unq;
+    if (h->stepped && h->unq != OWN_PREV) {
         if (!h->snapPL) {
-            HIPCHK(hipMalloc(&h->snapPL, sizeof(float) * h->cells));
-            HIPCHK(hipMalloc(&h->snapPD, sizeof(float) * h->cells));
+            HIPCHK(hipMalloc(&h->snapPL, pb));
+            HIPCHK(hipMalloc(&h->snapPD, pb));
         }
-        HIPCHK(hipMemcpyAsync(h->snapPL, h->L32[1 - h->cur], sizeof(float) * h->cells, hipMemcpyDeviceToDevice, h->stream));
-        HIPCHK(hipMemcpyAsync(h->snapPD, h->D32[1 - h->cur], sizeof(float) * h->cells, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->snapPL, h->L16[1 - h->cur], pb, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->snapPD, h->D16[1 - h->cur], pb, hipMemcpyDeviceToDevice, h->stream));
     }
     h->snap_agents = bn && h->have_agents;
     if (h->snap_agents) {
         HIPCHK(hipMemcpyAsync(h->snap_idx, h->idx, sizeof(int) * 2 * bn, hipMemcpyDeviceToDevice, h->stream));
         HIPCHK(hipMemcpyAsync(h->snap_st, h->st, sizeof(double) * bn, hipMemcpyDeviceToDevice, h->stream));
     }
-    h->snap_quantised = h->cur_quantised;
     h->snap_valid = true;
     return DW_OK;
 }
@@ -1710,22 +1732,22 @@ int dw_snapshot_restore(dw_handle* h) {
     NEED(h, DW_EINVAL, "null handle");
     const dw_params& p = h->prm;
     HIPCHK(hipSetDevice(p.device));
-    NEED(h->snap_valid, DW_ESTATE, "no snapshot saved");
+    NEED(h->snap_valid, DW_ESTATE, "no snapshot saved (or a later upload / dw_init_random invalidated it)");
     const size_t bn = (size_t)p.batch * p.n_agents;
-    HIPCHK(hipMemcpyAsync(h->L32[h->cur], h->snapL, sizeof(float) * h->cells, hipMemcpyDeviceToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->D32[h->cur], h->snapD, sizeof(float) * h->cells, hipMemcpyDeviceToDevice, h->stream));
+    const size_t pb = sizeof(plane_t) * h->cells;
+    HIPCHK(hipMemcpyAsync(h->L16[h->cur], h->snapL, pb, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->D16[h->cur], h->snapD, pb, hipMemcpyDeviceToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->stats2[h->sp], h->snap_stats, h->stats_bytes, hipMemcpyDeviceToDevice, h->stream));
     HIPCHK(hipMemsetAsync(h->stats2[1 - h->sp], 0, h->stats_bytes, h->stream));
     if (h->snap_agents) {
         HIPCHK(hipMemcpyAsync(h->idx, h->snap_idx, sizeof(int) * 2 * bn, hipMemcpyDeviceToDevice, h->stream));
         HIPCHK(hipMemcpyAsync(h->st, h->snap_st, sizeof(double) * bn, hipMemcpyDeviceToDevice, h->stream));
     }
-    if (h->snap_stepped && h->snap_f64 != F64_PREV) {
-        HIPCHK(hipMemcpyAsync(h->L32[1 - h->cur], h->snapPL, sizeof(float) * h->cells, hipMemcpyDeviceToDevice, h->stream));
-        HIPCHK(hipMemcpyAsync(h->D32[1 - h->cur], h->snapPD, sizeof(float) * h->cells, hipMemcpyDeviceToDevice, h->stream));
+    if (h->snap_stepped && h->snap_unq != OWN_PREV) {
+        HIPCHK(hipMemcpyAsync(h->L16[1 - h->cur], h->snapPL, pb, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->D16[1 - h->cur], h->snapPD, pb, hipMemcpyDeviceToDevice, h->stream));
     }
-    h->f64 = h->snap_f64;                       // F64_PREV: the float64 copy of the initial state is still there
-    h->cur_quantised = h->snap_quantised;
+    h->unq = h->snap_unq;                       // OWN_PREV: the un-quantised initial state is still in its buffers
     h->stepped = h->snap_stepped;
     h->L_last = h->snap_L_last;
     return DW_OK;
@@ -1770,8 +1792,10 @@ int dw_device_planes(dw_handle* h, int which, void** light, void** dark) {
     NEED(h && light && dark, DW_EINVAL, "null argument");
     NEED(which == DW_STATE_CURRENT || which == DW_STATE_PREVIOUS, DW_EINVAL, "bad state selector");
     const int buf = which == DW_STATE_CURRENT ? h->cur : 1 - h->cur;
-    *light = h->L32[buf];
-    *dark = h->D32[buf];
+    NEED(which != DW_STATE_CURRENT || cur_quantised(h), DW_ESTATE,
+         "the current state is an un-quantised upload: it has no binary16 planes before the first step");
+    *light = h->L16[buf];
+    *dark = h->D16[buf];
     return DW_OK;
 }
 
@@ -1791,9 +1815,8 @@ int dw_kernel_info(dw_handle* h, char* buf, size_t buflen) {
                  g.chunk * 8);
         if (h->allow_fuse) {
             const size_t n = std::strlen(buf);
-            snprintf(buf + n, buflen - n, "; dw_step_n fuses step pairs (step_stream_fused2%s%s)",
-                     p.precision == DW_PRECISION_EXACT ? "_exact" : "",
-                     h->allow_f16 ? ", binary16 planes between its launches" : "");
+            snprintf(buf + n, buflen - n, "; dw_step_n fuses step pairs (step_stream_fused2%s)",
+                     p.precision == DW_PRECISION_EXACT ? "_exact" : "");
         }
     } else if (h->tcq) {
         const int TR = (256 / h->tcq) * h->rpt;
@@ -1812,13 +1835,13 @@ int dw_audit_tie_bound(dw_handle* h, double L, double out[4]) {
     NEED(h && out, DW_EINVAL, "null argument");
     const dw_params& p = h->prm;
     HIPCHK(hipSetDevice(p.device));
-    NEED(h->have_state && h->cur_quantised, DW_ESTATE, "the audit needs a quantised current state");
+    NEED(h->have_state && cur_quantised(h), DW_ESTATE, "the audit needs a quantised current state");
     int rc = ensure_scratch(h, 4 * sizeof(unsigned long long));
     if (rc) return rc;
     unsigned long long* d = reinterpret_cast<unsigned long long*>(h->scratch);
     HIPCHK(hipMemsetAsync(d, 0, 4 * sizeof(unsigned long long), h->stream));
     const dim3 g((unsigned)((p.height * p.width + 255) / 256), (unsigned)p.batch);
-    hipLaunchKernelGGL(tie_audit, g, dim3(256), 0, h->stream, h->L32[h->cur], h->D32[h->cur], p.height, p.width,
+    hipLaunchKernelGGL(tie_audit, g, dim3(256), 0, h->stream, h->L16[h->cur], h->D16[h->cur], p.height, p.width,
                        derive_f32(p, L), make_f64(p, L), d);
     HIPCHK(hipGetLastError());
     unsigned long long r[4];

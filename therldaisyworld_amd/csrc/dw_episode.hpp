@@ -24,10 +24,10 @@ namespace dw {
 enum { kPolicyArgmax = 0, kPolicyArgmin = 1, kPolicyZeros = 2, kPolicyTable = 3, kPolicySkipAgents = 4 };
 
 struct EpisodeIO {
-    float* L;                       // [B][C] current planes (in/out)
-    float* D;
-    float* prevL;                   // [B][C] out: state before the last step (after its grazing)
-    float* prevD;
+    plane_t* L;                     // [B][C] current planes (in/out; binary16 in HBM, float32 in LDS)
+    plane_t* D;
+    plane_t* prevL;                 // [B][C] out: state before the last step (after its grazing)
+    plane_t* prevD;
     int* idx;                       // [B][N][2] in/out
     double* st;                     // [B][N] in/out
     const PhysF32* P32;             // [K]
@@ -91,8 +91,8 @@ __global__ __launch_bounds__(256) void episode_small(EpisodeIO io, int B, int N,
 
     if (valid) {
         for (int c = lt; c < C; c += tpw) {
-            curL[c] = io.L[(size_t)b * C + c];
-            curD[c] = io.D[(size_t)b * C + c];
+            curL[c] = (float)io.L[(size_t)b * C + c];
+            curD[c] = (float)io.D[(size_t)b * C + c];
         }
         for (int n = lt; n < N; n += tpw) {
             ast[n] = io.st[(size_t)b * N + n];
@@ -269,10 +269,10 @@ __global__ __launch_bounds__(256) void episode_small(EpisodeIO io, int B, int N,
 
     if (valid) {
         for (int c = lt; c < C; c += tpw) {
-            io.L[(size_t)b * C + c] = curL[c];
-            io.D[(size_t)b * C + c] = curD[c];
-            io.prevL[(size_t)b * C + c] = nxtL[c];
-            io.prevD[(size_t)b * C + c] = nxtD[c];
+            io.L[(size_t)b * C + c] = (plane_t)curL[c];
+            io.D[(size_t)b * C + c] = (plane_t)curD[c];
+            io.prevL[(size_t)b * C + c] = (plane_t)nxtL[c];
+            io.prevD[(size_t)b * C + c] = (plane_t)nxtD[c];
         }
         for (int n = lt; n < N; n += tpw) {
             io.st[(size_t)b * N + n] = ast[n];

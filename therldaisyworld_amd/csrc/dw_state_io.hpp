@@ -19,8 +19,8 @@ namespace dw {
 template <typename PrevT, bool POST>
 __global__ __launch_bounds__(256) void materialise(const PrevT* __restrict__ pL,
                                                    const PrevT* __restrict__ pD,
-                                                   const float* __restrict__ cL,
-                                                   const float* __restrict__ cD, int H, int W,
+                                                   const plane_t* __restrict__ cL,
+                                                   const plane_t* __restrict__ cD, int H, int W,
                                                    PhysF64 P, double* __restrict__ grid7,
                                                    double* __restrict__ temps,
                                                    double* __restrict__ betas,
@@ -39,8 +39,8 @@ __global__ __launch_bounds__(256) void materialise(const PrevT* __restrict__ pL,
         double* g = grid7 + (size_t)b * 7 * n + cell;
         if (POST) {
             g[0 * n] = dw_round3_k(P.p - o.nl - o.nd) / 1000.0;
-            g[1 * n] = (double)cL[woff + cell] / 1000.0;
-            g[2 * n] = (double)cD[woff + cell] / 1000.0;
+            g[1 * n] = to_natural(cL[woff + cell]);
+            g[2 * n] = to_natural(cD[woff + cell]);
             g[3 * n] = dw_round3_k(o.T) / 1000.0;
             g[4 * n] = dw_round3_k(o.Tl) / 1000.0;
             g[5 * n] = dw_round3_k(o.Td) / 1000.0;
@@ -89,18 +89,18 @@ __global__ void agents_stamp(double* __restrict__ grid7, const int* __restrict__
 //   out[2] = number of cells the tie test flags   out[3] = number of cells audited
 // (both species count).  Non-negative doubles order like their bit patterns: atomicMax on u64.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void tie_audit(const float* __restrict__ L, const float* __restrict__ D, int H, int W,
+__global__ __launch_bounds__(256) void tie_audit(const plane_t* __restrict__ L, const plane_t* __restrict__ D, int H, int W,
                                                  PhysF32 P, PhysF64 P64, unsigned long long* __restrict__ out) {
     const int b = blockIdx.y;
     const int cell = blockIdx.x * 256 + threadIdx.x;
     if (cell >= H * W) return;
     const size_t woff = (size_t)b * H * W;
-    const float* pl = L + woff;
-    const float* pd = D + woff;
+    const plane_t* pl = L + woff;
+    const plane_t* pd = D + woff;
     const int r = cell / W, c = cell - r * W;
     const int ru = r == 0 ? H - 1 : r - 1, rd = r == H - 1 ? 0 : r + 1;
     const int cl = c == 0 ? W - 1 : c - 1, cr = c == W - 1 ? 0 : c + 1;
-#define DW_AT(p, rr, cc) (p)[(size_t)(rr) * W + (cc)]
+#define DW_AT(p, rr, cc) (float)(p)[(size_t)(rr) * W + (cc)]
     const float li = DW_AT(pl, r, c), di = DW_AT(pd, r, c);
     const float El = (DW_AT(pl, ru, c) + DW_AT(pl, rd, c)) + (DW_AT(pl, r, cl) + DW_AT(pl, r, cr));
     const float Cl = (DW_AT(pl, ru, cl) + DW_AT(pl, rd, cl)) + (DW_AT(pl, ru, cr) + DW_AT(pl, rd, cr));
@@ -172,21 +172,21 @@ __global__ void init_random_agents(int* __restrict__ idx, double* __restrict__ s
 }
 
 // plane conversions
-__global__ void f64_to_permille(const double* __restrict__ in, float* __restrict__ out, size_t n) {
+// natural-unit float32 upload -> un-quantised per-mille float32 (in place allowed)
+__global__ void f32nat_to_permille(const float* __restrict__ in, float* __restrict__ out, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = (float)(in[i] * 1000.0);
+    if (i < n) out[i] = in[i] * 1000.f;
 }
-__global__ void f32nat_to_permille(const float* __restrict__ in, float* __restrict__ out, size_t n,
-                                   int quantise) {
+// natural-unit float32 upload of a QUANTISED state -> canonical binary16 plane
+__global__ void f32nat_to_plane(const float* __restrict__ in, plane_t* __restrict__ out, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) {
-        const float k = in[i] * 1000.f;
-        out[i] = quantise ? __builtin_rintf(k) : k;
-    }
+    if (i < n) out[i] = (plane_t)__builtin_rintf(in[i] * 1000.f);
 }
-__global__ void permille_to_f64(const float* __restrict__ in, double* __restrict__ out, size_t n) {
+// any plane format -> natural-unit float64 (downloads)
+template <typename T>
+__global__ void plane_to_f64(const T* __restrict__ in, double* __restrict__ out, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = (double)in[i] / 1000.0;
+    if (i < n) out[i] = to_natural(in[i]);
 }
 
 // stats of an arbitrary state (used after uploads / init so that dw_reduce is always valid)

@@ -13,10 +13,7 @@ namespace dw {
 // (kept only in a second 3-row register window, never written to memory) and, one row behind it,
 // one row of step-2 results, which is stored.  HBM traffic per cell-update drops to 8.25 B
 // (measured by PMC, profiles/), and the kernel becomes VALU-bound.
-// TI / TO: plane element type on the input / output side - float, or _Float16 for the states between
-// the launches of one dw_step_n / dw_run_episode call, which nothing else reads: a quantised state is
-// an integer <= 1000, exact in binary16 (4.13 B per cell-update).  The first launch of a run reads and
-// the last one writes float32.
+// Planes are binary16 on both sides (plane_t, dw_common.hpp): 4.13 HBM bytes per cell-update measured.
 //
 // Horizontal neighbours of step-1 results come from adjacent lanes by DPP like the inputs do.
 //   ROT (W == 256): the wave spans the whole torus row, all 64 lanes produce output.
@@ -112,7 +109,7 @@ constexpr int kMismatchCap = 64;            // float32 step-1 mismatches per wav
 //   pstats[2*world + 1] number of this world's output row groups (4 cells of a lane) holding a step-2
 //                       value above `thr_hi` that cannot be an artefact of float32 or be undone by the few
 //                       cells patched afterwards - a sound lower bound, see agents_lookahead_patch.
-template <bool ROT, bool EXACT, bool PACK = false, bool STATS = false, typename TI = float, typename TO = float>
+template <bool ROT, bool EXACT, bool PACK = false, bool STATS = false, typename TI = plane_t, typename TO = plane_t>
 __device__ __forceinline__ void fused2_body(const TI* __restrict__ inL, const TI* __restrict__ inD,
                                             TO* __restrict__ outL, TO* __restrict__ outD, const FusedGeom& G,
                                             const PhysF32& P1, const PhysF32& P2, const PhysF64& P64,
@@ -172,7 +169,7 @@ __device__ __forceinline__ void fused2_body(const TI* __restrict__ inL, const TI
     const TI* pL = inL + woff;
     const TI* pD = inD + woff;
 
-    struct RawIn { decltype(stream_load4_raw(pL)) l, d; };      // one row of both planes as loaded (float4 or 4 x binary16)
+    struct RawIn { dw_f16x4 l, d; };                            // one row of both planes as loaded (4 x binary16 each)
     auto load_raw = [&](int rr) -> RawIn {                      // rr in [r0-2, r0+nr+1], clamped + wrapped
         rr = min(rr, r0 + nr + 1);
         rr = rr < 0 ? rr + G.H : rr;
@@ -556,28 +553,25 @@ __device__ __forceinline__ void fused2_body(const TI* __restrict__ inL, const TI
     }
 }
 
-template <bool ROT, bool PACK = false, bool STATS = false, typename TI = float, typename TO = float>
-__global__ __launch_bounds__(256) void step_stream_fused2(const float* __restrict__ inL, const float* __restrict__ inD,
-                                                          float* __restrict__ outL, float* __restrict__ outD,
+template <bool ROT, bool PACK = false, bool STATS = false>
+__global__ __launch_bounds__(256) void step_stream_fused2(const plane_t* __restrict__ inL, const plane_t* __restrict__ inD,
+                                                          plane_t* __restrict__ outL, plane_t* __restrict__ outD,
                                                           FusedGeom G, PhysF32 P1, PhysF32 P2,
                                                           unsigned long long* __restrict__ zero_me, int zero_n,
                                                           unsigned int* __restrict__ pstats, float thr_hi) {
     const PhysF64 dummy{};
     const double zero = 0.0;
-    fused2_body<ROT, false, PACK, STATS, TI, TO>(reinterpret_cast<const TI*>(inL), reinterpret_cast<const TI*>(inD),
-                                                 reinterpret_cast<TO*>(outL), reinterpret_cast<TO*>(outD), G, P1, P2, dummy,
-                                                 zero, zero, zero_me, zero_n, pstats, thr_hi);
+    fused2_body<ROT, false, PACK, STATS>(inL, inD, outL, outD, G, P1, P2, dummy, zero, zero, zero_me, zero_n, pstats, thr_hi);
 }
 
-// Waves per SIMD of the exact kernels: the variant with binary16 planes on both sides (every launch of a long
-// dw_step_n run but the first and the last) fits 3 waves/SIMD (165-168 VGPRs); the others would spill
-// 44-80 B per lane there (measured 30 % slower) and stay at 2.
-template <bool PACK, bool STATS, typename TI, typename TO>
+// Waves per SIMD of the exact kernels: the plain variants fit 3 waves/SIMD (153-155 VGPRs); the packed and
+// STATS variants would spill 44-80 B per lane there (measured 30 % slower) and stay at 2.
+template <bool PACK, bool STATS>
 constexpr int fused_exact_waves() {
-    return (!PACK && !STATS && std::is_same<TI, _Float16>::value && std::is_same<TO, _Float16>::value) ? 3 : 2;
+    return (!PACK && !STATS) ? 3 : 2;
 }
 struct FusedExactArgs {
-    const float* inL; const float* inD; float* outL; float* outD;     // float32 or binary16 planes (TI / TO)
+    const plane_t* inL; const plane_t* inD; plane_t* outL; plane_t* outD;
     FusedGeom G;
     PhysF32 P1; PhysLumF32 lum2;                                  // step 2 = P1 with these members replaced:
                                                                   // 15 shared constants instead of 2 x 23 (each
@@ -587,15 +581,14 @@ struct FusedExactArgs {
     PhysF64 P64; double La; double Lb;                            // cold (see kernarg_struct)
 };
 
-template <bool ROT, bool PACK = false, bool STATS = false, typename TI = float, typename TO = float>
+template <bool ROT, bool PACK = false, bool STATS = false>
 __global__ __launch_bounds__(256)
-__attribute__((amdgpu_waves_per_eu(fused_exact_waves<PACK, STATS, TI, TO>(), fused_exact_waves<PACK, STATS, TI, TO>())))
+__attribute__((amdgpu_waves_per_eu(fused_exact_waves<PACK, STATS>(), fused_exact_waves<PACK, STATS>())))
 void step_stream_fused2_exact(FusedExactArgs A) {
     const FusedExactArgs& cold = kernarg_struct<FusedExactArgs>();
     const PhysF32 P2 = with_lum(A.P1, A.lum2);
-    fused2_body<ROT, true, PACK, STATS, TI, TO>(reinterpret_cast<const TI*>(A.inL), reinterpret_cast<const TI*>(A.inD),
-                                                reinterpret_cast<TO*>(A.outL), reinterpret_cast<TO*>(A.outD), A.G, A.P1, P2,
-                                                cold.P64, cold.La, cold.Lb, A.zero_me, A.zero_n, A.pstats, A.thr_hi);
+    fused2_body<ROT, true, PACK, STATS>(A.inL, A.inD, A.outL, A.outD, A.G, A.P1, P2, cold.P64, cold.La, cold.Lb, A.zero_me,
+                                        A.zero_n, A.pstats, A.thr_hi);
 }
 
 }  // namespace dw

@@ -1,5 +1,6 @@
-// dw_step_generic.hpp — step_generic: one thread per cell, any grid shape, float64 or float32: the
-// in-library reference, the first step from an un-quantised state, odd shapes.
+// dw_step_generic.hpp — step_generic: one thread per cell, any grid shape, float64 or float32 arithmetic: the
+// in-library reference, the first step from an un-quantised state (InT = double / float), odd shapes.
+// Input: any plane format (dw_common.hpp); output: always the canonical binary16 planes.
 #pragma once
 #include "dw_common.hpp"
 
@@ -11,8 +12,8 @@ namespace dw {
 template <typename InT, int PREC>
 __global__ __launch_bounds__(256) void step_generic(const InT* __restrict__ inL,
                                                     const InT* __restrict__ inD,
-                                                    float* __restrict__ outL,
-                                                    float* __restrict__ outD, int H, int W,
+                                                    plane_t* __restrict__ outL,
+                                                    plane_t* __restrict__ outD, int H, int W,
                                                     PhysF32 P, PhysF64 P64,
                                                     StatsDev* __restrict__ stats,
                                                     unsigned long long* __restrict__ fixups,
@@ -42,9 +43,9 @@ __global__ __launch_bounds__(256) void step_generic(const InT* __restrict__ inL,
 #define DW_AT(p, rr, cc) to_permille((p)[(size_t)(rr) * W + (cc)])
             const float li = DW_AT(pl, r, c), di = DW_AT(pd, r, c);
             const float El = (DW_AT(pl, ru, c) + DW_AT(pl, rd, c)) + (DW_AT(pl, r, cl) + DW_AT(pl, r, cr));
-            const float Cl = (DW_AT(pl, ru, cl) + DW_AT(pl, rd, cl)) + (DW_AT(pl, ru, cr) + DW_AT(pl, rd, cr));
+            const float Cl = (DW_AT(pl, ru, cl) + DW_AT(pl, ru, cr)) + (DW_AT(pl, rd, cl) + DW_AT(pl, rd, cr));   // pairs as cells4
             const float Ed = (DW_AT(pd, ru, c) + DW_AT(pd, rd, c)) + (DW_AT(pd, r, cl) + DW_AT(pd, r, cr));
-            const float Cd = (DW_AT(pd, ru, cl) + DW_AT(pd, rd, cl)) + (DW_AT(pd, ru, cr) + DW_AT(pd, rd, cr));
+            const float Cd = (DW_AT(pd, ru, cl) + DW_AT(pd, ru, cr)) + (DW_AT(pd, rd, cl) + DW_AT(pd, rd, cr));
 #undef DW_AT
             const GrowthF32 g = growth_f32<PREC != 1 || kFastSplit>(P, li, di, El, Cl, Ed, Cd);
             if (PREC == 1) {
@@ -65,8 +66,8 @@ __global__ __launch_bounds__(256) void step_generic(const InT* __restrict__ inL,
                 }
             }
         }
-        outL[woff + cell] = kl;
-        outD[woff + cell] = kd;
+        outL[woff + cell] = (plane_t)kl;
+        outD[woff + cell] = (plane_t)kd;
     }
     // per-world reductions: wave shuffles, then one set of atomics per wave
     const float m = wave_max(fmaxf(kl, kd));

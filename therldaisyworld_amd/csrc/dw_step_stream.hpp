@@ -9,13 +9,13 @@ namespace dw {
 // step_stream — the hot kernel for wide grids (W >= 256): wave-strip streaming.
 //
 // Every WAVE owns a strip of 256 columns x SR rows of one world and marches down it; a lane owns 4
-// adjacent columns.  Rows are loaded straight into registers with one coalesced 16-byte load per
-// lane and plane, three rows ahead of their use (the data is touched exactly once, so an LDS round
+// adjacent columns.  Rows are loaded straight into registers with one coalesced 8-byte load (four
+// binary16 cells) per lane and plane, three rows ahead of their use (the data is touched exactly once, so an LDS round
 // trip would be pure overhead — cdna_hip_programming.md §5 "streamed once per block": load straight
 // to VGPRs, deep prefetch, late vmcnt).  The 3x3 stencil is a 3-row register window; horizontal
 // neighbours come from the adjacent lanes with DPP wavefront shifts (v_mov_b32_dpp wave_shr/shl),
 // and the one column to the left / right of the strip arrives either by a wavefront ROTATE (W = 256:
-// the toroidal wrap is inside the wave) or with one extra 4-byte load per row and plane in which
+// the toroidal wrap is inside the wave) or with one extra 2-byte load per row and plane in which
 // lanes 0-31 fetch the left halo column and lanes 32-63 the right one (the DPP "old" operand then
 // drops them into lanes 0 and 63).  No barrier in the loop: waves run independently.
 //
@@ -49,49 +49,6 @@ struct StripGeom {
     int qcap;                 // near-tie LDS queue capacity in use (<= kWaveQueueCap; tests shrink it)
     int lpw, wpr;             // packed mode (W < 256): lanes per world row (W/4), worlds per wave row (64 / lpw)
 };
-
-// streaming accesses of the hot kernel.  The new planes are not read again within the step, so they
-// are stored non-temporally; non-temporal LOADS were measured slower (-DDW_NT_LOAD keeps the switch).
-typedef float dw_f32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ float4 stream_load4(const float* p) {
-#ifdef DW_NT_LOAD
-    const dw_f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const dw_f32x4*>(p));
-    return make_float4(v.x, v.y, v.z, v.w);
-#else
-    return *reinterpret_cast<const float4*>(p);
-#endif
-}
-__device__ __forceinline__ void stream_store4(float* p, const float4& v) {
-#ifndef DW_NO_NT_STORE      // non-temporal stores: measured -1.5 % (fast) / -6 % (exact) on C2
-    dw_f32x4 t;
-    t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
-    __builtin_nontemporal_store(t, reinterpret_cast<dw_f32x4*>(p));
-#else
-    *reinterpret_cast<float4*>(p) = v;
-#endif
-}
-
-// binary16 planes (the intermediate states of a dw_step_n run, dw_step_fused.hpp): a quantised state is an
-// integer in [0, 1000], exactly representable in binary16 (integers up to 2048 are), so the conversion
-// is lossless whatever its rounding mode; one v_cvt_pkrtz_f16_f32 packs two cells.
-typedef _Float16 dw_f16x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int dw_u32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ float4 stream_load4(const _Float16* p) {
-    const dw_f16x4 v = *reinterpret_cast<const dw_f16x4*>(p);
-    return make_float4((float)v.x, (float)v.y, (float)v.z, (float)v.w);
-}
-// the same load WITHOUT the conversion: the fused kernels keep a prefetched row as loaded and widen it where it
-// is consumed, an iteration later (a conversion placed next to the load would wait for it at once)
-__device__ __forceinline__ dw_f16x4 stream_load4_raw(const _Float16* p) { return *reinterpret_cast<const dw_f16x4*>(p); }
-__device__ __forceinline__ float4 stream_load4_raw(const float* p) { return stream_load4(p); }
-__device__ __forceinline__ float4 widen4(const dw_f16x4& v) { return make_float4((float)v.x, (float)v.y, (float)v.z, (float)v.w); }
-__device__ __forceinline__ float4 widen4(const float4& v) { return v; }
-__device__ __forceinline__ void stream_store4(_Float16* p, const float4& v) {
-    dw_u32x2 t;
-    t.x = __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_pkrtz(v.x, v.y));
-    t.y = __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_pkrtz(v.z, v.w));
-    __builtin_nontemporal_store(t, reinterpret_cast<dw_u32x2*>(p));
-}
 
 struct Raw {                  // one row as loaded: own 4 columns of both planes + the halo column values
     float4 l, d;
@@ -222,8 +179,8 @@ __device__ __forceinline__ void queue_tie(bool tie, unsigned int& n, uint4* __re
 }
 
 template <bool EXACT, int HALO, int RB>
-__device__ __forceinline__ void stream_body(const float* __restrict__ inL, const float* __restrict__ inD,
-                                            float* __restrict__ outL, float* __restrict__ outD, const StripGeom& G,
+__device__ __forceinline__ void stream_body(const plane_t* __restrict__ inL, const plane_t* __restrict__ inD,
+                                            plane_t* __restrict__ outL, plane_t* __restrict__ outD, const StripGeom& G,
                                             const PhysF32& P, const PhysF64& P64, StatsDev* __restrict__ stats,
                                             unsigned long long* __restrict__ fixups,
                                             unsigned long long* __restrict__ zero_me, int zero_n) {
@@ -258,8 +215,8 @@ __device__ __forceinline__ void stream_body(const float* __restrict__ inL, const
     const int colq = PACK ? 4 * pj : c0 + 4 * min(lane, last_lane);   // inactive lanes shadow the last active one
     int hcol = lane < 32 ? c0 - 1 : c0 + 4 * ncq;           // halo column of this lane's half-wave
     hcol = hcol < 0 ? hcol + G.W : (hcol >= G.W ? hcol - G.W : hcol);
-    const float* pL = inL + woff;
-    const float* pD = inD + woff;
+    const plane_t* pL = inL + woff;
+    const plane_t* pD = inD + woff;
     const int last_row = r0 + nr;                           // one past the strip: the bottom halo row
     float acc_max = 0.f, acc_l = 0.f, acc_d = 0.f;
     unsigned int nq = 0;                                    // entries queued by this wave (uniform)
@@ -267,12 +224,12 @@ __device__ __forceinline__ void stream_body(const float* __restrict__ inL, const
     auto load_raw = [&](int rr) -> Raw {                    // rr in [r0-1, r0+nr], clamped + wrapped
         rr = min(rr, last_row);
         rr = rr < 0 ? rr + G.H : (rr >= G.H ? rr - G.H : rr);
-        const float* rl = pL + (size_t)rr * G.W;
-        const float* rd = pD + (size_t)rr * G.W;
+        const plane_t* rl = pL + (size_t)rr * G.W;
+        const plane_t* rd = pD + (size_t)rr * G.W;
         Raw w;
         w.l = stream_load4(rl + colq);
         w.d = stream_load4(rd + colq);
-        if (HALO == 1 || HALO == 2) { w.hl = rl[hcol]; w.hd = rd[hcol]; } else { w.hl = 0.f; w.hd = 0.f; }
+        if (HALO == 1 || HALO == 2) { w.hl = (float)rl[hcol]; w.hd = (float)rd[hcol]; } else { w.hl = 0.f; w.hd = 0.f; }
         return w;
     };
     auto to_rows = [&](const Raw& w, Row4& L, Row4& D) {
@@ -350,8 +307,8 @@ __device__ __forceinline__ void stream_body(const float* __restrict__ inL, const
                 const NewCoverF64 o = cell_f64_lean(P64, w);
                 const float kl = (float)dw_round3_k(o.nl), kd = (float)dw_round3_k(o.nd);
                 const size_t off = (size_t)e0.x * G.H * G.W + (size_t)(e0.y >> 16) * G.W + (e0.y & 0xffffu);
-                outL[off] = kl;                             // after this wave's own float4 store of the row
-                outD[off] = kd;
+                outL[off] = (plane_t)kl;                    // after this wave's own row store (see wait_row_stores_before_patching)
+                outD[off] = (plane_t)kd;
                 if (PACK) {                                 // the entry's world is not this lane's: straight to its counters
                     atomicMax(&stats[e0.x].max_k, (unsigned int)fmaxf(kl, kd));
                     atomicAdd(&stats[e0.x].sum_l, (unsigned long long)(long long)(kl - (float)(f32v & 0xffffu)));
@@ -382,8 +339,8 @@ __device__ __forceinline__ void stream_body(const float* __restrict__ inL, const
                 gather9(inD + wo, G.H, G.W, r, c, d9);
                 const CellF64 o = cell_f64(P64, l9, d9);
                 const float kl = (float)dw_round3_k(o.nl), kd = (float)dw_round3_k(o.nd);
-                outL[wo + (size_t)r * G.W + c] = kl;
-                outD[wo + (size_t)r * G.W + c] = kd;
+                outL[wo + (size_t)r * G.W + c] = (plane_t)kl;
+                outD[wo + (size_t)r * G.W + c] = (plane_t)kd;
                 if (PACK) {
                     atomicMax(&stats[wi].max_k, (unsigned int)fmaxf(kl, kd));
                     atomicAdd(&stats[wi].sum_l, (unsigned long long)kl);
@@ -439,8 +396,8 @@ __device__ __forceinline__ void stream_body(const float* __restrict__ inL, const
 // fix-up path and is planned for 3 waves per SIMD (<= 168 VGPRs; its 48 KB of LDS queues per
 // workgroup allow 3 workgroups per CU as well).
 template <int HALO>
-__global__ __launch_bounds__(256) void step_stream_fast(const float* __restrict__ inL, const float* __restrict__ inD,
-                                                        float* __restrict__ outL, float* __restrict__ outD,
+__global__ __launch_bounds__(256) void step_stream_fast(const plane_t* __restrict__ inL, const plane_t* __restrict__ inD,
+                                                        plane_t* __restrict__ outL, plane_t* __restrict__ outD,
                                                         StripGeom G, PhysF32 P, PhysF64 P64,
                                                         StatsDev* __restrict__ stats,
                                                         unsigned long long* __restrict__ fixups,
@@ -458,7 +415,7 @@ __device__ __forceinline__ const A& kernarg_struct() {          // A is the kern
 }
 
 struct StreamExactArgs {
-    const float* inL; const float* inD; float* outL; float* outD;
+    const plane_t* inL; const plane_t* inD; plane_t* outL; plane_t* outD;
     StripGeom G; PhysF32 P; StatsDev* stats; unsigned long long* fixups; unsigned long long* zero_me; int zero_n;
     PhysF64 P64;                                                  // cold
 };

@@ -1,5 +1,6 @@
 // dw_step_tiled.hpp — step_tiled: LDS-staged tile with halo (grids with W < 256, W % 4 == 0), its
-// global near-tie queues and the float64 fix-up / tile-redo kernels of the exact mode.
+// global near-tie queues and the float64 fix-up / tile-redo kernels of the exact mode.  Binary16 planes in
+// HBM (8-byte groups of four cells), float32 tile in LDS.
 #pragma once
 #include "dw_common.hpp"
 
@@ -56,7 +57,7 @@ struct TileCfg {
 #ifdef DW_TUNING
 // plain streaming copy of both planes: the achievable-bandwidth yardstick for this traffic shape
 __global__ __launch_bounds__(256) void copy_planes(const float4* __restrict__ inL, const float4* __restrict__ inD,
-                                                   float4* __restrict__ outL, float4* __restrict__ outD, size_t n4) {
+                                                   float4* __restrict__ outL, float4* __restrict__ outD, size_t n4) {   // n4: 16-byte groups
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n4) { outL[i] = inL[i]; outD[i] = inD[i]; }
 }
@@ -64,10 +65,10 @@ __device__ int g_ablate;   // 0 normal, 1 skip the arithmetic (stage -> LDS -> r
 #endif
 
 template <int TCQ, int RPT, bool EXACT>
-__global__ __launch_bounds__(256) void step_tiled(const float* __restrict__ inL,
-                                                  const float* __restrict__ inD,
-                                                  float* __restrict__ outL,
-                                                  float* __restrict__ outD, Geom G, PhysF32 P,
+__global__ __launch_bounds__(256) void step_tiled(const plane_t* __restrict__ inL,
+                                                  const plane_t* __restrict__ inD,
+                                                  plane_t* __restrict__ outL,
+                                                  plane_t* __restrict__ outD, Geom G, PhysF32 P,
                                                   StatsDev* __restrict__ stats,
                                                   unsigned long long* __restrict__ fixups,
                                                   unsigned long long* __restrict__ zero_me,
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(256) void step_tiled(const float* __restrict__ inL,
     // ---- phase 1: stage tile + halo into LDS (all loads issued before the first LDS write) ----
     {
         const int lrows = nrows + 2, lq = nq + 2;
-        float4 vl[C::STAGE_ITERS], vd[C::STAGE_ITERS];
+        dw_f16x4 vl[C::STAGE_ITERS], vd[C::STAGE_ITERS];
 #pragma unroll
         for (int it = 0; it < C::STAGE_ITERS; ++it) {
             const int idx = it * 256 + tid;
@@ -109,16 +110,16 @@ __global__ __launch_bounds__(256) void step_tiled(const float* __restrict__ inL,
             int gg = q0 - 1 + gq;
             gg = gg < 0 ? gg + G.Wq : (gg >= G.Wq ? gg - G.Wq : gg);
             const size_t off = woff + (size_t)rr * G.W + (size_t)gg * 4;
-            vl[it] = *reinterpret_cast<const float4*>(inL + off);
-            vd[it] = *reinterpret_cast<const float4*>(inD + off);
+            vl[it] = stream_load4_raw(inL + off);
+            vd[it] = stream_load4_raw(inD + off);
         }
 #pragma unroll
         for (int it = 0; it < C::STAGE_ITERS; ++it) {
             const int idx = it * 256 + tid;
             const int j = idx / C::LQ, gq = idx - j * C::LQ;
             if (j < lrows && gq < lq) {
-                *reinterpret_cast<float4*>(lds + j * C::LSTRIDE + gq * 4) = vl[it];
-                *reinterpret_cast<float4*>(lds + C::PLANE + j * C::LSTRIDE + gq * 4) = vd[it];
+                *reinterpret_cast<float4*>(lds + j * C::LSTRIDE + gq * 4) = widen4(vl[it]);
+                *reinterpret_cast<float4*>(lds + C::PLANE + j * C::LSTRIDE + gq * 4) = widen4(vd[it]);
             }
         }
     }
@@ -167,8 +168,8 @@ __global__ __launch_bounds__(256) void step_tiled(const float* __restrict__ inL,
                     }
                 }
                 const size_t off = woff + (size_t)(r0 + row) * G.W + (size_t)(q0 + cq) * 4;
-                *reinterpret_cast<float4*>(outL + off) = make_float4(ol[0], ol[1], ol[2], ol[3]);
-                *reinterpret_cast<float4*>(outD + off) = make_float4(od[0], od[1], od[2], od[3]);
+                stream_store4(outL + off, make_float4(ol[0], ol[1], ol[2], ol[3]));
+                stream_store4(outD + off, make_float4(od[0], od[1], od[2], od[3]));
                 if (EXACT && ties) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(256) void step_tiled(const float* __restrict__ inL,
 // by (float64 result - float32 result) and contribute to the per-world max (the main kernel kept
 // near-tie cells out of the max).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void fixup_cells(float* __restrict__ outL, float* __restrict__ outD, int H, int W,
+__global__ __launch_bounds__(256) void fixup_cells(plane_t* __restrict__ outL, plane_t* __restrict__ outD, int H, int W,
                                                    PhysF64 P64, StatsDev* __restrict__ stats, FixQ fq) {
     const unsigned int q = blockIdx.y;
     const unsigned int n = min(fq.counts[q * 16], fq.qcap);
@@ -270,8 +271,8 @@ __global__ __launch_bounds__(256) void fixup_cells(float* __restrict__ outL, flo
             dl = kl - (float)(e2.w & 0xffffu);
             dd = kd - (float)(e2.w >> 16);
             const size_t off = (size_t)world * H * W + (size_t)r * W + c;
-            outL[off] = kl;
-            outD[off] = kd;
+            outL[off] = (plane_t)kl;
+            outD[off] = (plane_t)kd;
         }
     }
     // per-world reductions: entries of one tile are contiguous, so a wave holds few distinct worlds
@@ -293,8 +294,8 @@ __global__ __launch_bounds__(256) void fixup_cells(float* __restrict__ outL, flo
 
 // redo_tiles_f64 — exact mode, third kernel of a step (normally a no-op): whole tiles whose
 // near-tie queue overflowed are recomputed in float64 from the pre-step planes.  grid = fixed.
-__global__ __launch_bounds__(256) void redo_tiles_f64(const float* __restrict__ inL, const float* __restrict__ inD,
-                                                      float* __restrict__ outL, float* __restrict__ outD, Geom G,
+__global__ __launch_bounds__(256) void redo_tiles_f64(const plane_t* __restrict__ inL, const plane_t* __restrict__ inD,
+                                                      plane_t* __restrict__ outL, plane_t* __restrict__ outD, Geom G,
                                                       int TR, int TCQ, PhysF64 P64, StatsDev* __restrict__ stats,
                                                       FixQ fq) {
     const unsigned int nredo = fq.counts[kNumQueues * 16];
@@ -316,8 +317,8 @@ __global__ __launch_bounds__(256) void redo_tiles_f64(const float* __restrict__ 
             gather9(inD + woff, G.H, G.W, r, c, d9);
             const CellF64 o = cell_f64(P64, l9, d9);
             const float kl = (float)dw_round3_k(o.nl), kd = (float)dw_round3_k(o.nd);
-            outL[woff + (size_t)r * G.W + c] = kl;
-            outD[woff + (size_t)r * G.W + c] = kd;
+            outL[woff + (size_t)r * G.W + c] = (plane_t)kl;
+            outD[woff + (size_t)r * G.W + c] = (plane_t)kd;
             atomicMax(&s_max, (unsigned int)fmaxf(kl, kd));
             atomicAdd(&s_suml, (unsigned int)kl);
             atomicAdd(&s_sumd, (unsigned int)kd);

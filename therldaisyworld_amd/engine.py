@@ -162,6 +162,12 @@ class Engine:
                                   int(bool(use_device_actions))))
         return Lc.value
 
+    def last_step_n_timing(self):
+        """(ms spent in the fused step-pair launches of the last step_n call, their number, plane element bytes)."""
+        ms, n, eb = C.c_float(0), C.c_int32(0), C.c_int32(0)
+        self._check(self._lib.dw_last_step_n_timing(self._h, C.byref(ms), C.byref(n), C.byref(eb)))
+        return ms.value, n.value, eb.value
+
     def update_agents(self, action):
         a = self._actions(action)
         self._check(self._lib.dw_update_agents(self._h, _ffi.ptr_i(a), a.shape[0], a.shape[1]))

@@ -1,26 +1,29 @@
 #!/bin/bash
-# Round profile on the GPU box: bench line, rocprofv3 kernel stats and the HBM-traffic PMC passes.
-#   usage (from the repo root, on the box):  bash tools/profile_round.sh <tag>      e.g. r01e
-# Outputs under gpurun_out/prof_<tag>/ ; tools/traffic_from_pmc.py turns the PMC CSVs into profiles/traffic_*.json.
-# (counters in their own passes with --kernel-trace only; the program itself follows `--`.)
-# The --stats pass runs bench.py's default 512 steps after 64 of warm-up, so that its per-kernel average is
-# comparable with the bench line (shorter runs see clocks that are still rising: +8..20 % per launch).
+# Round profile on the GPU box for ONE workload of bench.py: bench line, rocprofv3 kernel stats, the HBM-traffic
+# PMC passes and the SQ (VALU) counter passes, both arithmetic modes.
+#   usage (from the repo root, on the box):  bash tools/profile_round.sh <tag> <workload> [steps]     e.g. r02a target 21
+# Outputs under gpurun_out/prof_<tag>_<workload>/ ; tools/profile_summarise.py turns them into profiles/*.
+# Counters run in their own passes with --kernel-trace only, and the program itself follows `--` (python3, no
+# wrapper): see the task statement's rules for rocprofv3 on this pool.
 set -e -o pipefail
 TAG=${1:-rXX}
+WL=${2:-target}
+STEPS=${3:-21}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$R/gpurun_out/prof_$TAG
+OUT=$R/gpurun_out/prof_${TAG}_${WL}
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-python3 "$R/bench.py" > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
-for prec in fast exact; do
+COMMON="--workload $WL --warmup 4 --no-cpu-baseline --no-modes --no-workloads --preheat-s 0.3"
+for prec in exact fast; do
   rocprofv3 --kernel-trace --stats -d "$OUT/stats_$prec" -o s --output-format csv -- \
-      python3 "$R/bench.py" --steps 512 --warmup 64 --precision $prec --no-cpu-baseline --no-modes \
+      python3 "$R/bench.py" $COMMON --steps $((STEPS * 3)) --preheat-s 1.5 --precision $prec \
       > "$OUT/stats_$prec.json" 2> "$OUT/stats_$prec.err"
-  for ctr in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --kernel-trace --pmc $ctr -d "$OUT/pmc_${prec}_$ctr" -o p --output-format csv -- \
-        python3 "$R/bench.py" --steps 13 --warmup 3 --precision $prec --no-cpu-baseline --no-modes \
-        > "$OUT/pmc_${prec}_$ctr.json" 2> "$OUT/pmc_${prec}_$ctr.err"
+  echo "stats $prec done"
+  for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU" "SQ_INSTS_VALU_TRANS_F32 GRBM_GUI_ACTIVE" "SQ_BUSY_CYCLES SQ_WAVE_CYCLES"; do
+    name=$(echo $set | tr ' ' '+')
+    rocprofv3 --kernel-trace --pmc $set -d "$OUT/pmc_${prec}_$name" -o p --output-format csv -- \
+        python3 "$R/bench.py" $COMMON --steps $STEPS --precision $prec \
+        > "$OUT/pmc_${prec}_$name.json" 2> "$OUT/pmc_${prec}_$name.err"
+    echo "pmc $prec $name done"
   done
-  echo "profiled $prec"
 done
-cat "$OUT/bench_default.json"
