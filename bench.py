@@ -304,7 +304,7 @@ def main():
         L = min_L
         t_pre = time.perf_counter()
         pre_steps = 0
-        chunk = max(2, min(64, warmup or 8))
+        chunk = 64                                          # 31 fused launches + 2 single steps per call
         while time.perf_counter() - t_pre < preheat_s:
             L = run(chunk, L, 0.0)
             eng.sync()

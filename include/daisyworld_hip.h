@@ -235,6 +235,12 @@ int dw_update_agents(dw_handle* h, const int32_t* action, int32_t action_b, int3
 int dw_forward_f64(dw_handle* h, const double* light, const double* dark, double L, double* grid7,
                    double* temps, double* betas, double* growth, double* temp_effective);
 
+/* One 3x3 toroidal convolution of a caller-supplied float64 plane [B][H][W] with the 9 row-major kernel weights -
+ * exactly the operation of ft_convolve (ref daisy/nn/functional.py:12-49, a true convolution on the torus) that
+ * calculate_albedo (ref :377-394) and calculate_daisy_density (ref :423-432) are built from; the drop-in's
+ * stand-alone calculate_* methods call it.  Does not touch the handle's state. */
+int dw_conv3x3_f64(dw_handle* h, const double* plane, const double kernel[9], double* out);
+
 /* Observations (ref get_obs :246-263): [B][N][7][3][3] float64 for the handle's agents, taken from
  * the current grid exactly as dw_download_grid would materialise it, times the neighbourhood mask. */
 int dw_get_obs(dw_handle* h, double L_init, double* obs);

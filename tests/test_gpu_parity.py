@@ -81,6 +81,42 @@ def test_forward_matches_reference_fixture_g1(amd, golden, tag):
     eng.close()
 
 
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_dropin_stage_methods_g1(amd, golden, tag):
+    """calculate_albedo / _daisy_density / _temperature / _growth_rate / _growth as stand-alone methods of the
+    drop-in (ref :340-432), chained like forward() chains them, against the side-effect caches the reference left
+    after forward() on the same grid (fixture G1) and stage by stage against the oracle's restatement.  The
+    stencil stages convolve on the device (direct 9-tap form of the reference's FFT convolution: ~1e-15)."""
+    g = golden("G1_forward")
+    gi = g[f"{tag}_grid_in"].copy()
+    env = amd.RLDaisyWorld(grid_dimension=16, n_agents=2)
+    env.batch_size = 2
+    env.reset()
+    env.L = float(g[f"{tag}_L"])
+    P = O.Params(grid_dimension=16, n_agents=2, batch_size=2)
+    Al, A = env.calculate_albedo(gi[:, :3])
+    oAl, oA = O.calculate_albedo(P, g[f"{tag}_grid_in"][:, :3].copy())
+    np.testing.assert_allclose(Al, oAl, rtol=1e-14, atol=0)
+    np.testing.assert_allclose(A, oA, rtol=1e-13, atol=0)
+    assert np.array_equal(gi[:, 0], env.p - gi[:, 1] - gi[:, 2])      # channel 0 rewritten in place (ref :381)
+    dens = env.calculate_daisy_density(gi[:, 1:3])
+    np.testing.assert_allclose(dens, O.calculate_daisy_density(P, g[f"{tag}_grid_in"][:, 1:3]), rtol=1e-13, atol=1e-300)
+    t, tl, td = env.calculate_temperature(Al, A)
+    for ours, name in ((t, "temp"), (tl, "temp_light"), (td, "temp_dark"), (env.temp_effective, "temp_effective"),
+                       (env.dead_temp, "dead_temp"), (env.temp, "temp")):
+        np.testing.assert_allclose(ours, g[f"{tag}_{name}"], rtol=1e-12, atol=0)
+    b, bl, bd = env.calculate_growth_rate(t, tl, td)
+    for ours, name in ((b, "beta"), (bl, "beta_l"), (bd, "beta_d"), (env.beta_l, "beta_l")):
+        np.testing.assert_allclose(ours, g[f"{tag}_{name}"], rtol=1e-9, atol=1e-12)
+    gr = env.calculate_growth(b, bl, bd, dens)
+    np.testing.assert_allclose(gr, g[f"{tag}_growth"], rtol=1e-9, atol=1e-14)
+    assert env.growth is gr or np.array_equal(env.growth, gr)
+    # the new covers forward() would produce from these stages equal the reference's (ref :449-452)
+    new = np.round(np.clip(gi[:, 1:3] + env.dt * gr, 0, 1), 3)
+    assert np.array_equal(new, g[f"{tag}_grid_out"][:, 1:3])
+    env.close()
+
+
 # ---------------------------------------------------------------------------------------------
 # one step from a quantised state: all three precisions x kernel shapes
 # ---------------------------------------------------------------------------------------------

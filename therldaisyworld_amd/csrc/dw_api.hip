@@ -257,11 +257,20 @@ static PhysF32 derive_f32(const dw_params& p, double L, int hb_cap = 40) {
     split_hi_lo(a3, scale, &P.a3h, &P.a3l);
     split_hi_lo(a4, scale, &P.a4h, &P.a4l);
     split_hi_lo(c0l, scale, &P.c0lh, &P.c0ll);
-    split_hi_lo(c0d, scale, &P.c0dh, &P.c0dl);
+    float c0dl;
+    split_hi_lo(c0d, scale, &P.c0dh, &c0dl);
+    P.dc0l = c0dl - P.c0ll;                                      // the lo chain carries light's lo constant
+    // float32-only mode: every coefficient rounded once (= fl(hi + lo): the sum of two floats is exact in double)
+    P.a1 = (float)((double)P.a1h + P.a1l); P.a2 = (float)((double)P.a2h + P.a2l);
+    P.a3 = (float)((double)P.a3h + P.a3l); P.a4 = (float)((double)P.a4h + P.a4l);
+    P.c0ls = (float)((double)P.c0lh + P.c0ll); P.c0ds = (float)((double)P.c0dh + c0dl);
     P.cbeta = (float)(p.g * p.temp_optimal * p.temp_optimal);
     const PhysF64 P64 = make_f64(p, L);
-    P.w0 = (float)P64.w0; P.w1 = (float)P64.w1; P.w2 = (float)P64.w2;
-    P.p = (float)p.p; P.gamma = (float)p.gamma; P.dt = (float)p.dt;
+    // dt folded into the density weights (dK = dt * density is what the map needs); the bare fraction then is
+    // kb = p - (dKl + dKd) * 0.001 / dt  (dt = 0: no growth at all - weights 0, kb = p)
+    P.dw0 = (float)(p.dt * P64.w0); P.dw1 = (float)(p.dt * P64.w1); P.dw2 = (float)(p.dt * P64.w2);
+    P.p = (float)p.p; P.ck = p.dt != 0.0 ? (float)(0.001 / p.dt) : 0.f;
+    P.ngamma = (float)(-p.gamma);
     // ---- tie bound (per-mille), DESIGN.md "Exact mode":
     //   |gq32 - gq64| <= A0 + eA*|gq| + |dt*K| * (eK0 + eK1*om),   om = 1 - beta >= 0
     const double u = std::ldexp(1.0, -24);
@@ -1196,6 +1205,28 @@ int dw_forward_f64(dw_handle* h, const double* light, const double* dark, double
     const hipError_t se = hipStreamSynchronize(h->stream);
     if (le == hipSuccess) le = se;
     if (le != hipSuccess) return fail(DW_EHIP, "dw_forward_f64: %s", hipGetErrorString(le));
+    return DW_OK;
+}
+
+int dw_conv3x3_f64(dw_handle* h, const double* plane, const double kernel[9], double* out) {
+    NEED(h && plane && kernel && out, DW_EINVAL, "null argument");
+    const dw_params& p = h->prm;
+    HIPCHK(hipSetDevice(p.device));
+    const size_t n = h->cells;
+    int rc = ensure_scratch(h, sizeof(double) * 2 * n);
+    if (rc) return rc;
+    double* d_in = h->scratch;
+    double* d_out = d_in + n;
+    Kernel9 K;
+    for (int i = 0; i < 9; ++i) K.k[i] = kernel[i];
+    SyncOnExit guard(h->stream);                              // `plane` / `out` are the caller's
+    HIPCHK(hipMemcpyAsync(d_in, plane, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
+    const dim3 g((unsigned)((p.height * p.width + 255) / 256), (unsigned)p.batch);
+    hipLaunchKernelGGL(conv3x3_f64, g, dim3(256), 0, h->stream, d_in, d_out, p.height, p.width, K);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, d_out, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    guard.disarm();
     return DW_OK;
 }
 

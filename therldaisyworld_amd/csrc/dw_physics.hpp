@@ -149,32 +149,52 @@ __device__ inline NewCoverF64 cell_f64_lean(const PhysF64& P, const unsigned int
 //  * the fourth root is taken on u = 1 + e as y = sqrt(sqrt(u)), but the deviation from the
 //    optimum temperature is formed as  (T_x - To)/To = y - 1 = e / ((y + 1)(y^2 + 1)),  which keeps
 //    the RELATIVE accuracy of e instead of cancelling two numbers near 1.
+// Constant PAIRS.  The hot kernels evaluate two cells per lane with packed float32 instructions, whose operands
+// are 64-bit: a wave-uniform constant splatted from ONE scalar register would occupy a whole SGPR pair (and an
+// instruction may read only one scalar pair, so a second constant had to be copied into VGPRs).  Constants are
+// therefore stored two to an 8-byte-aligned pair; the packed form selects the low or the high half for BOTH
+// lanes with the instruction's op_sel bits (free), and constants that meet in one instruction share a pair.
+// This halves the SGPR footprint of a coefficient set (the exact fused kernel spilled ~27 SGPRs into VGPR
+// lanes and paid ~3 v_readlane per cell-evaluation for them).  Each pair is also addressable as two floats.
+typedef float dw_f32x2 __attribute__((ext_vector_type(2)));
+#define DW_PAIR(lo_name, hi_name, pair_name) \
+    union { struct { float lo_name, hi_name; }; dw_f32x2 pair_name; }
+
 struct PhysF32 {
-    float a1h, a2h, a3h, a4h;    // hi parts of the affine coefficients (per per-mille unit)
-    float a1l, a2l, a3l, a4l;    // lo parts
-    float c0lh, c0ll;            // constant for light, hi / lo
-    float c0dh, c0dl;            // constant for dark
-    float cbeta;                 // g * To^2:  beta = 1 - cbeta * ((T-To)/To)^2
-    float w0, w1, w2;            // daisy kernel weights
-    float p, gamma, dt;
+    // e_x = c0x + a1*Sl8 + a2*Sd8 + a3*li + a4*di, coefficients split hi + lo (exact mode) ...
+    DW_PAIR(a1h, a2h, a12h);
+    DW_PAIR(a3h, a4h, a34h);
+    DW_PAIR(a1l, a2l, a12l);
+    DW_PAIR(a3l, a4l, a34l);
+    DW_PAIR(c0lh, c0ll, c0l);    // constant for light: hi, lo (the lo part seeds the lo chain)
+    DW_PAIR(c0dh, dc0l, c0d);    // constant for dark: hi, and (its lo part - light's lo part)
+    // ... or rounded once (float32-only mode): a_i = fl(a_ih + a_il), c0x = fl(c0xh + c0xl)
+    DW_PAIR(a1, a2, a12);
+    DW_PAIR(a3, a4, a34);
+    DW_PAIR(c0ls, c0ds, c0s);
+    // dt * (daisy kernel weights): dK = dt * density comes straight out of the weighted sum
+    DW_PAIR(dw0, dw1, dw01);
+    DW_PAIR(dw2, cbeta, dw2cb);  // cbeta = g * To^2:  beta = 1 - cbeta * ((T-To)/To)^2
+    DW_PAIR(p, ck, pck);         // bare fraction kb = p - (dKl + dKd) * ck,  ck = 0.001 / dt
     // exact-mode tie test (per-mille; om = 1 - beta = cbeta*((T-To)/To)^2 >= 0):
     //   |frac(gq)| > tie_lo - eA*|gq| - |dt*K|*(eK0 + eK1*om)   =>  re-evaluate in float64
-    float tie_lo, eA, eK0, eK1;
-    float eK0s, eK1s;            // -sign(dt) * eK0, eK1: dK * (eK0s + eK1s*om) = -|dK| * (eK0 + eK1*om) (density >= 0)
+    DW_PAIR(eK1s, eK0s, eKs);    // -sign(dt) * eK1, eK0: dK * (eK0s + eK1s*om) = -|dK| * (eK0 + eK1*om) (density >= 0)
+    DW_PAIR(ngamma, tie_lo, gt); // -gamma; the tie threshold's constant part
+    float eA, eK0, eK1;          // eA is used un-packed (|gq| source modifier); eK0 / eK1: host, audit
     int hi_bits;                 // the hi parts are multiples of 2^-hi_bits (host bookkeeping)
 };
+static_assert(sizeof(PhysF32) == 32 * sizeof(float), "PhysF32 layout");
 
 // the members of PhysF32 that depend on the luminosity (the rest is shared by the two steps of a fused
 // launch when both coefficient sets are split at the same scale, see derive_f32_pair() in dw_api.hip)
 struct PhysLumF32 {
-    float a1h, a2h, a1l, a2l, c0lh, c0ll, c0dh, c0dl;
+    dw_f32x2 a12h, a12l, c0l, c0d, a12, c0s;
 };
 __host__ __device__ inline PhysLumF32 lum_part(const PhysF32& P) {
-    return PhysLumF32{P.a1h, P.a2h, P.a1l, P.a2l, P.c0lh, P.c0ll, P.c0dh, P.c0dl};
+    return PhysLumF32{P.a12h, P.a12l, P.c0l, P.c0d, P.a12, P.c0s};
 }
 __host__ __device__ inline PhysF32 with_lum(PhysF32 P, const PhysLumF32& l) {
-    P.a1h = l.a1h; P.a2h = l.a2h; P.a1l = l.a1l; P.a2l = l.a2l;
-    P.c0lh = l.c0lh; P.c0ll = l.c0ll; P.c0dh = l.c0dh; P.c0dl = l.c0dl;
+    P.a12h = l.a12h; P.a12l = l.a12l; P.c0l = l.c0l; P.c0d = l.c0d; P.a12 = l.a12; P.c0s = l.c0s;
     return P;
 }
 
@@ -185,7 +205,6 @@ __host__ __device__ inline PhysF32 with_lum(PhysF32 P, const PhysLumF32& l) {
 // Floating-point contraction is switched off and every fused multiply-add is spelled out, so both
 // instantiations perform the SAME correctly-rounded operations in the same order: all kernels produce
 // bit-identical values whichever form they use.
-typedef float dw_f32x2 __attribute__((ext_vector_type(2)));
 
 template <typename T> struct Lanes;
 template <> struct Lanes<float> {
@@ -200,6 +219,8 @@ template <> struct Lanes<float> {
     static __device__ __forceinline__ void gt(float a, float b, bool* out) { out[0] = a > b; }
     static __device__ __forceinline__ float load(const float* a, int i) { return a[i]; }
     static __device__ __forceinline__ float fma_abs(float a, float b, float c) { return __builtin_fmaf(a, __builtin_fabsf(b), c); }
+    static __device__ __forceinline__ float lo(dw_f32x2 pair) { return pair.x; }   // the two constants of a pair
+    static __device__ __forceinline__ float hi(dw_f32x2 pair) { return pair.y; }
 };
 template <> struct Lanes<dw_f32x2> {
     static constexpr int N = 2;
@@ -219,6 +240,9 @@ template <> struct Lanes<dw_f32x2> {
     static __device__ __forceinline__ T fma_abs(float a, T b, float c) {
         return T{__builtin_fmaf(a, __builtin_fabsf(b.x), c), __builtin_fmaf(a, __builtin_fabsf(b.y), c)};
     }
+    // one half of a constant pair for both cells: folds into the packed instruction's op_sel / op_sel_hi bits
+    static __device__ __forceinline__ T lo(dw_f32x2 pair) { return __builtin_shufflevector(pair, pair, 0, 0); }
+    static __device__ __forceinline__ T hi(dw_f32x2 pair) { return __builtin_shufflevector(pair, pair, 1, 1); }
 };
 
 template <typename T>
@@ -248,47 +272,45 @@ __device__ __forceinline__ GrowthT<T> growth_t(const PhysF32& P, T li, T di, T E
     const T Sl8 = El + Cl, Sd8 = Ed + Cd;
     T el, ed;
     if (SPLIT) {
-        T hi = T(P.a1h) * Sl8;
-        hi = V::fma(T(P.a2h), Sd8, hi);
-        hi = V::fma(T(P.a3h), li, hi);
-        hi = V::fma(T(P.a4h), di, hi);
-        T lo = T(P.a1l) * Sl8;
-        lo = V::fma(T(P.a2l), Sd8, lo);
-        lo = V::fma(T(P.a3l), li, lo);
-        lo = V::fma(T(P.a4l), di, lo);
-        el = (hi + T(P.c0lh)) + (lo + T(P.c0ll));
-        ed = (hi + T(P.c0dh)) + (lo + T(P.c0dl));
+        T hi = V::lo(P.a12h) * Sl8;                         // exact for integer inputs (see above)
+        hi = V::fma(V::hi(P.a12h), Sd8, hi);
+        hi = V::fma(V::lo(P.a34h), li, hi);
+        hi = V::fma(V::hi(P.a34h), di, hi);
+        T lo = V::fma(V::lo(P.a12l), Sl8, V::hi(P.c0l));    // the lo chain starts from light's lo constant
+        lo = V::fma(V::hi(P.a12l), Sd8, lo);
+        lo = V::fma(V::lo(P.a34l), li, lo);
+        lo = V::fma(V::hi(P.a34l), di, lo);
+        el = (hi + V::lo(P.c0l)) + lo;
+        ed = (hi + V::lo(P.c0d)) + (lo + V::hi(P.c0d));
     } else {
-        T base = T(P.a1h + P.a1l) * Sl8;                    // coefficient sums are wave-uniform (hoisted)
-        base = V::fma(T(P.a2h + P.a2l), Sd8, base);
-        base = V::fma(T(P.a3h + P.a3l), li, base);
-        base = V::fma(T(P.a4h + P.a4l), di, base);
-        el = base + T(P.c0lh + P.c0ll);
-        ed = base + T(P.c0dh + P.c0dl);
+        T base = V::lo(P.a12) * Sl8;
+        base = V::fma(V::hi(P.a12), Sd8, base);
+        base = V::fma(V::lo(P.a34), li, base);
+        base = V::fma(V::hi(P.a34), di, base);
+        el = base + V::lo(P.c0s);
+        ed = base + V::hi(P.c0s);
     }
     // light
     const T sl = V::sqrt(one + el);
     const T yl = V::sqrt(sl);
     const T dl = el * V::rcp((yl + one) * (sl + one));
-    const T cdl = T(P.cbeta) * dl;
+    const T cdl = V::hi(P.dw2cb) * dl;
     const T bl = V::fma(-cdl, dl, one);                     // beta_l = 1 - cbeta*dl^2
     // dark
     const T sd = V::sqrt(one + ed);
     const T yd = V::sqrt(sd);
     const T dd = ed * V::rcp((yd + one) * (sd + one));
-    const T cdd = T(P.cbeta) * dd;
+    const T cdd = V::hi(P.dw2cb) * dd;
     const T bd = V::fma(-cdd, dd, one);
-    // densities (per-mille) and bare fraction (natural)
-    const T Kl = V::fma(T(P.w2), Cl, V::fma(T(P.w1), El, T(P.w0) * li));
-    const T Kd = V::fma(T(P.w2), Cd, V::fma(T(P.w1), Ed, T(P.w0) * di));
-    const T kb = V::fma(-(Kl + Kd), T(0.001f), T(P.p));
+    // dt * densities (per-mille) and the bare fraction (natural)
     GrowthT<T> o;
+    o.dKl = V::fma(V::lo(P.dw2cb), Cl, V::fma(V::hi(P.dw01), El, V::lo(P.dw01) * li));
+    o.dKd = V::fma(V::lo(P.dw2cb), Cd, V::fma(V::hi(P.dw01), Ed, V::lo(P.dw01) * di));
+    const T kb = V::fma(-(o.dKl + o.dKd), V::hi(P.pck), V::lo(P.pck));
     o.oml = cdl * dl;                                       // only the exact mode's tie bound reads these
     o.omd = cdd * dd;
-    o.dKl = T(P.dt) * Kl;
-    o.dKd = T(P.dt) * Kd;
-    o.gql = o.dKl * V::fma(kb, bl, T(-P.gamma));
-    o.gqd = o.dKd * V::fma(kb, bd, T(-P.gamma));
+    o.gql = o.dKl * V::fma(kb, bl, V::lo(P.gt));
+    o.gqd = o.dKd * V::fma(kb, bd, V::lo(P.gt));
     return o;
 }
 
@@ -315,7 +337,7 @@ __device__ __forceinline__ T finish_exact_t(const PhysF32& P, T k, T gq, T dK, T
     using V = Lanes<T>;
     const T r = V::rint(gq);
     const T frac = V::abs(gq - r);                          // exact (Sterbenz)
-    const T thr = V::fma(dK, V::fma(T(P.eK1s), om, T(P.eK0s)), V::fma_abs(-P.eA, gq, P.tie_lo));
+    const T thr = V::fma(dK, V::fma(V::lo(P.eKs), om, V::hi(P.eKs)), V::fma_abs(-P.eA, gq, P.tie_lo));
     V::gt(frac, thr, tie);
     return V::clip(k + r);
 }

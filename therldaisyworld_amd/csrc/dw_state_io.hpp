@@ -171,6 +171,32 @@ __global__ void init_random_agents(int* __restrict__ idx, double* __restrict__ s
     st[an] = 1.0;
 }
 
+// conv3x3_f64 — ref ft_convolve (daisy/nn/functional.py:12-49) for a 3x3 kernel: the toroidal TRUE convolution
+// out[i][j] = sum_{a,b} k[a][b] * x[i-(a-1)][j-(b-1)] it computes by FFT, evaluated directly in
+// float64, row-major taps in ascending (a, b).  Serves the stand-alone calculate_albedo / calculate_daisy_density
+// methods of the drop-in; the step kernels never call it (they fuse both stencils).
+struct Kernel9 { double k[9]; };
+__global__ __launch_bounds__(256) void conv3x3_f64(const double* __restrict__ x, double* __restrict__ out, int H, int W,
+                                                   Kernel9 K) {
+    const int b = blockIdx.y;
+    const int cell = blockIdx.x * 256 + threadIdx.x;
+    if (cell >= H * W) return;
+    const size_t woff = (size_t)b * H * W;
+    const int i = cell / W, j = cell - i * W;
+    double acc = 0.0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const int ii = (i - (a - 1) + H) % H;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            if (K.k[a * 3 + c] == 0.0) continue;
+            const int jj = (j - (c - 1) + W) % W;
+            acc += K.k[a * 3 + c] * x[woff + (size_t)ii * W + jj];
+        }
+    }
+    out[woff + cell] = acc;
+}
+
 // plane conversions
 // natural-unit float32 upload -> un-quantised per-mille float32 (in place allowed)
 __global__ void f32nat_to_permille(const float* __restrict__ in, float* __restrict__ out, size_t n) {

@@ -553,8 +553,13 @@ __device__ __forceinline__ void fused2_body(const TI* __restrict__ inL, const TI
     }
 }
 
+// Waves per SIMD the float32-only fused kernels are planned for (the register allocator's budget: 128 VGPRs at 4)
+#ifndef DW_FUSED_FAST_WAVES
+#define DW_FUSED_FAST_WAVES 4
+#endif
 template <bool ROT, bool PACK = false, bool STATS = false>
-__global__ __launch_bounds__(256) void step_stream_fused2(const plane_t* __restrict__ inL, const plane_t* __restrict__ inD,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DW_FUSED_FAST_WAVES, DW_FUSED_FAST_WAVES)))
+void step_stream_fused2(const plane_t* __restrict__ inL, const plane_t* __restrict__ inD,
                                                           plane_t* __restrict__ outL, plane_t* __restrict__ outD,
                                                           FusedGeom G, PhysF32 P1, PhysF32 P2,
                                                           unsigned long long* __restrict__ zero_me, int zero_n,

@@ -275,23 +275,38 @@ __device__ __forceinline__ void stream_body(const plane_t* __restrict__ inL, con
             queue_tie<3>(tie[3], nq, q, (unsigned)G.qcap, world, r0 + k, colq, upL, miL, dnL, upD, miD, dnD, ol, od);
         }
     };
-    int k = 0;
-    for (; k + RB <= nr; k += RB) {
-        Raw nx[RB];
-#pragma unroll
-        for (int j = 0; j < RB; ++j) nx[j] = load_raw(r0 + k + RB + 1 + j);
+    // One block = RB (2) rows: prefetch the two rows the NEXT block needs, compute the two rows of this one from the
+    // four-row window, then drop the prefetched rows into the two window slots that just became free.  The window
+    // is a ring: the block alternates between the slot orders (0,1,2,3) and (2,3,0,1) - written out as two
+    // phases - instead of shifting rows from slot to slot (32 register moves per block: 4 of the 49 VALU
+    // instructions per cell-update of the float32 kernel).
+    static_assert(RB == 2, "the ring below is written for two-row blocks");
+    auto block = [&](auto PHc, int kk) {
+        constexpr int PH = decltype(PHc)::value;           // physical slot of the block's first window row
+        constexpr int s0 = PH, s1 = (PH + 1) & 3, s2 = (PH + 2) & 3, s3 = (PH + 3) & 3;
+        Raw nx[2];
+        nx[0] = load_raw(r0 + kk + 3);
+        nx[1] = load_raw(r0 + kk + 4);
         __builtin_amdgcn_sched_barrier(0);                  // loads first, then the arithmetic
-#pragma unroll
-        for (int j = 0; j < RB; ++j) row_math(WL[j], WL[j + 1], WL[j + 2], WD[j], WD[j + 1], WD[j + 2], k + j);
+        row_math(WL[s0], WL[s1], WL[s2], WD[s0], WD[s1], WD[s2], kk);
+        row_math(WL[s1], WL[s2], WL[s3], WD[s1], WD[s2], WD[s3], kk + 1);
         __builtin_amdgcn_sched_barrier(0);
-        WL[0] = WL[RB]; WD[0] = WD[RB];
-        WL[1] = WL[RB + 1]; WD[1] = WD[RB + 1];
-#pragma unroll
-        for (int j = 0; j < RB; ++j) to_rows(nx[j], WL[2 + j], WD[2 + j]);
+        to_rows(nx[0], WL[s0], WD[s0]);                     // rows kk+3, kk+4: window rows 2, 3 of the next block
+        to_rows(nx[1], WL[s1], WD[s1]);
+    };
+    using PH0 = std::integral_constant<int, 0>;
+    using PH2 = std::integral_constant<int, 2>;
+    int k = 0;
+    for (; k + 4 <= nr; k += 4) {
+        block(PH0{}, k);
+        block(PH2{}, k + 2);
     }
-#pragma unroll
-    for (int j = 0; j < RB - 1; ++j)                        // tail: < RB rows left, already in the window
-        if (k + j < nr) row_math(WL[j], WL[j + 1], WL[j + 2], WD[j], WD[j + 1], WD[j + 2], k + j);
+    bool odd_phase = false;
+    if (k + 2 <= nr) { block(PH0{}, k); k += 2; odd_phase = true; }
+    if (k < nr) {                                           // one row left, already in the window
+        if (odd_phase) row_math(WL[2], WL[3], WL[0], WD[2], WD[3], WD[0], k);
+        else row_math(WL[0], WL[1], WL[2], WD[0], WD[1], WD[2], k);
+    }
     if (HALO >= 2 && !active) { acc_max = 0.f; acc_l = 0.f; acc_d = 0.f; }
 
     // ---- exact mode: float64 re-evaluation of this wave's queued near-tie cells ----

@@ -399,6 +399,72 @@ class RLDaisyWorld:
         self._cache_src = (light, dark, self.L)
         return new_grid
 
+    # ------------------------------------------------------------------------------------------
+    # the stages of forward() as stand-alone methods (ref :340-432).  forward() / step() never call these:
+    # the device evaluates the fused map.  The two stencil stages run their convolutions on the device
+    # (dw_conv3x3_f64: the direct form of ft_convolve); the three pointwise stages are the reference's float64
+    # expressions on the caller's arrays.  Like the reference they refresh temp / beta / growth.
+    # ------------------------------------------------------------------------------------------
+    def _conv(self, x, kernel):
+        """ft_convolve(x, kernel) (ref nn/functional.py:12-49) for x of shape (B,1,H,W)."""
+        return self._ensure_engine().conv3x3(np.asarray(x, dtype=np.float64)[:, 0], np.asarray(kernel)[0, 0])[:, None]
+
+    def calculate_albedo(self, groundcover):
+        """ref :377-394: (local_albedo, adjacent_albedo), both (B,1,H,W); rewrites channel 0 in place (:381)."""
+        groundcover[:, 0, ...] = self.p - groundcover[:, 1, :, :] - groundcover[:, 2, :, :]
+        local_albedo = np.zeros((self.batch_size, 1, self.dim, self.dim))
+        adjacent_albedo = np.zeros((self.batch_size, 1, self.dim, self.dim))
+        for ii, albedo in enumerate([self.albedo_bare, self.albedo_light, self.albedo_dark]):
+            local_albedo += albedo * groundcover[:, ii:ii + 1, :, :]
+            adjacent_albedo += albedo * self._conv(groundcover[:, ii:ii + 1, :, :], self.adjacent_albedo_kernel)
+        return local_albedo, adjacent_albedo
+
+    def calculate_daisy_density(self, local_daisies):
+        """ref :423-432: (B,2,H,W) densities of light and dark daisies under the daisy kernel."""
+        daisy_density = np.zeros((self.batch_size, 2, self.dim, self.dim))
+        for jj in range(self.n_daisies):
+            daisy_density[:, jj:jj + 1, :, :] = self._conv(local_daisies[:, jj:jj + 1, :, :], self.daisy_kernel)
+        return daisy_density
+
+    def calculate_temperature(self, local_albedo, adjacent_albedo):
+        """ref :396-421: (temp, temp_light, temp_dark); refreshes temp_effective / temp* / dead_temp."""
+        Al, A = local_albedo, adjacent_albedo
+        temp_effective = ((self.S * self.L * (1 - A)) / self.sigma) ** (1 / 4)
+        temp = (self.q * (A - Al) + temp_effective ** 4) ** (1 / 4)
+        light_temp = (self.q2 * (Al - self.albedo_light) + temp ** 4) ** (1 / 4)
+        dark_temp = (self.q2 * (Al - self.albedo_dark) + temp ** 4) ** (1 / 4)
+        self._L_pass = self.L                                 # dead_temp follows the luminosity of this pass
+        self._stage_caches(temp_effective=temp_effective, temp=temp, temp_light=light_temp, temp_dark=dark_temp)
+        return temp, light_temp, dark_temp
+
+    def calculate_growth_rate(self, temp, temp_l, temp_d):
+        """ref :340-348."""
+        beta = 1 - self.g * (self.temp_optimal - temp) ** 2
+        beta_l = 1 - self.g * (self.temp_optimal - temp_l) ** 2
+        beta_d = 1 - self.g * (self.temp_optimal - temp_d) ** 2
+        self._stage_caches(beta=beta, beta_l=beta_l, beta_d=beta_d)
+        return beta, beta_l, beta_d
+
+    def calculate_growth(self, beta, beta_l, beta_d, daisy_density):
+        """ref :350-375 (the branch that uses beta is dead code in the reference, :362-364)."""
+        a_l = daisy_density[:, 0, :, :]
+        a_d = daisy_density[:, 1, :, :]
+        a_b = self.p - a_l - a_d
+        growth = np.zeros_like(daisy_density)
+        growth[:, 0, ...] = a_l * (a_b * beta_l.squeeze() - self.gamma)
+        growth[:, 1, ...] = a_d * (a_b * beta_d.squeeze() - self.gamma)
+        self._stage_caches(growth=growth)
+        return growth
+
+    def _stage_caches(self, **values):
+        """The stand-alone stages overwrite the side-effect caches one by one, as the reference's do."""
+        if not self._caches:
+            try:
+                self._cache("temp")                           # materialise the others before overriding some
+            except Exception:
+                self._caches = {}
+        self._caches = dict(self._caches, **values)
+
     def update_L(self, L):
         """ref :463-473 (host float64 scalar)."""
         self.step_count += 1

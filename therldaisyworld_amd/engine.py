@@ -195,6 +195,14 @@ class Engine:
                                        _ffi.ptr_d(t), _ffi.ptr_d(b), _ffi.ptr_d(g), _ffi.ptr_d(e)))
         return (grid, t, b, g, e) if want_caches else grid
 
+    def conv3x3(self, plane, kernel):
+        """Toroidal 3x3 convolution of a (B,H,W) float64 plane on the device (ref ft_convolve)."""
+        x = self._plane(plane, np.float64)
+        k = np.ascontiguousarray(kernel, dtype=np.float64).reshape(9)
+        out = np.empty_like(x)
+        self._check(self._lib.dw_conv3x3_f64(self._h, _ffi.ptr_d(x), _ffi.ptr_d(k), _ffi.ptr_d(out)))
+        return out
+
     def get_obs(self, L_init=0.75):
         obs = np.zeros((self.B, self.N, 7, 3, 3))
         if self.B * self.N:

@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--asm", default=os.path.join(OUT, "dw_api-hip-amdgcn-amd-amdhsa-gfx950.s"))
     ap.add_argument("--kernel", default="")
     ap.add_argument("--loop", action="store_true")
+    ap.add_argument("--dump", default="", help="write the hot loop of the (single) selected kernel to this file")
     ap.add_argument("--flag", action="append", default=[], help="extra compiler flag for --build (repeatable)")
     a = ap.parse_args()
     path = build(a.flag) if a.build else a.asm
@@ -116,13 +117,14 @@ def main():
                 mm = re.match(r"(\.LBB\S+):", ln)
                 if mm:
                     labels[mm.group(1)] = i
-            best = None
+            best, best_pk = None, -1
             for i, ln in enumerate(lines):
                 mm = re.match(r"\ts_cbranch_\S+ (\.LBB\S+)", ln) or re.match(r"\ts_branch (\.LBB\S+)", ln)
                 if mm and mm.group(1) in labels and labels[mm.group(1)] < i:
                     span = (labels[mm.group(1)], i)
-                    if best is None or span[1] - span[0] > best[1] - best[0]:
-                        best = span
+                    npk = sum(1 for x in lines[span[0]:span[1] + 1] if x.startswith("\tv_pk_"))   # the map's loop
+                    if npk > best_pk:
+                        best, best_pk = span, npk
             if best:
                 hist = collections.Counter()
                 n = 0
@@ -132,12 +134,14 @@ def main():
                         hist[classify(mm.group(1))] += 1
                         n += 1
                 valu = sum(c for k, c in hist.items() if k.startswith("v_"))
-                print(f"      largest loop: {n} instructions, {valu} VALU: " +
+                if a.dump:
+                    open(a.dump, "w").write("\n".join(lines[best[0]:best[1] + 1]) + "\n")
+                print(f"      hot loop (most packed float32): {n} instructions, {valu} VALU: " +
                       ", ".join(f"{k} {c}" for k, c in sorted(hist.items(), key=lambda kv: -kv[1])))
             scr = [ln.strip() for ln in lines if re.match(r"\tscratch_", ln)]
             if scr:
                 inloop = sum(1 for i, ln in enumerate(lines) if re.match(r"\tscratch_", ln) and best and best[0] <= i <= best[1])
-                print(f"      scratch instructions: {len(scr)} ({inloop} inside the largest loop)")
+                print(f"      scratch instructions: {len(scr)} ({inloop} inside the hot loop (most packed float32))")
 
 
 if __name__ == "__main__":
