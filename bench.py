@@ -14,9 +14,12 @@ environment launches the N ranks itself (children only: the parent never touches
 Default workload: the north-star shape, 1024 worlds of 4096x4096 on ONE GPU (128 GiB of binary16 ping-pong
 state; if the allocation fails the world count is halved until it fits and the line says so).  The C2
 workload (BASELINE configs[1], 1024 x 256^2) is measured in the same invocation and reported under
-"workloads".  Headline arithmetic mode: `exact` (float32 + float64 re-evaluation of near-tie cells:
-bit-identical to the float64 reference, the mode whose parity is pinned); `fast` (float32 only) is measured
-too and reported under "modes".
+"workloads".  Arithmetic modes: the headline is `fast` - float32 arithmetic, the "stated fp32 tolerance" of the
+north star: from identical states every cell within one quantum (1e-3) and >= 99.98 % of the cell values
+identical per step (measured >= 99.994 % on developed states over the whole luminosity ramp,
+profiles/r02_fast_tolerance.json; asserted by tests/test_gpu_parity.py); `exact` - float32 plus a float64
+re-evaluation of every near-tie cell, bit-identical to the float64 reference and the default of the drop-in
+class - is measured in the same invocation and reported under "modes".
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with these extra objects:
   roofline     per launch of the dominant kernel (the fused step-pair kernel: one launch = 2 steps):
@@ -66,9 +69,9 @@ def parse(argv=None):
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--workload", default="target", choices=sorted(WORKLOADS))
     ap.add_argument("--worlds", type=int, default=0, help="override worlds per GPU")
-    ap.add_argument("--precision", default="exact", choices=["exact", "fast", "f64"],
-                    help="arithmetic mode of the headline number (default exact: bit-identical to the float64 "
-                         "reference; the other of exact/fast is measured too and reported under 'modes')")
+    ap.add_argument("--precision", default="fast", choices=["exact", "fast", "f64"],
+                    help="arithmetic mode of the headline number (default fast = float32 within the stated, tested "
+                         "tolerance; the other of exact/fast is measured too and reported under 'modes')")
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--preheat-s", type=float, default=2.0,
                     help="seconds of untimed stepping before the warm-up steps, so that a short timed region does "
@@ -387,8 +390,10 @@ def main():
         "dtype": {"exact": "f32", "fast": "f32", "f64": "f64"}[args.precision],
         "data": "synthetic (device Philox initial state with the distribution of initialize_grid; ramped luminosity)",
         "config": {"workload": f"{args.workload}: {m['desc']}", "worlds_per_gpu": B, "grid": [G, G], "agents_per_world": N,
-                   "precision": args.precision + (" (float32 + float64 re-evaluation of near-tie cells: bit-identical to the "
-                                                  "float64 reference)" if args.precision == "exact" else ""),
+                   "precision": args.precision + {
+                       "exact": " (float32 + float64 re-evaluation of near-tie cells: bit-identical to the float64 reference)",
+                       "fast": " (float32: per step every cell within 1e-3 and >= 99.98 % of the cell values identical to the "
+                               "float64 reference, profiles/r02_fast_tolerance.json)"}.get(args.precision, ""),
                    "plane_format": "binary16 per-mille (lossless for the quantised state)", "kernel": m["kernel"],
                    "total_worlds": int(all_stats.shape[0]),
                    "parallelism": f"ensemble shard x{n_gpus} (no data-path collective)"},

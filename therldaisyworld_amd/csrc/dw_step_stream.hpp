@@ -50,9 +50,9 @@ struct StripGeom {
     int lpw, wpr;             // packed mode (W < 256): lanes per world row (W/4), worlds per wave row (64 / lpw)
 };
 
-struct Raw {                  // one row as loaded: own 4 columns of both planes + the halo column values
-    float4 l, d;
-    float hl, hd;             // lanes 0-31: column left of the strip; lanes 32-63: column right of it
+struct Raw {                  // one row AS LOADED (binary16: 6 VGPRs; widened where it is consumed): own 4 columns
+    dw_f16x4 l, d;            // of both planes
+    plane_t hl, hd;           // halo column values - lanes 0-31: column left of the strip; lanes 32-63: right of it
 };
 
 constexpr int kDppWaveShl1 = 0x130, kDppWaveRol1 = 0x134, kDppWaveShr1 = 0x138, kDppWaveRor1 = 0x13C;
@@ -227,17 +227,18 @@ __device__ __forceinline__ void stream_body(const plane_t* __restrict__ inL, con
         const plane_t* rl = pL + (size_t)rr * G.W;
         const plane_t* rd = pD + (size_t)rr * G.W;
         Raw w;
-        w.l = stream_load4(rl + colq);
-        w.d = stream_load4(rd + colq);
-        if (HALO == 1 || HALO == 2) { w.hl = (float)rl[hcol]; w.hd = (float)rd[hcol]; } else { w.hl = 0.f; w.hd = 0.f; }
+        w.l = stream_load4_raw(rl + colq);
+        w.d = stream_load4_raw(rd + colq);
+        if (HALO == 1 || HALO == 2) { w.hl = rl[hcol]; w.hd = rd[hcol]; } else { w.hl = (plane_t)0.f; w.hd = (plane_t)0.f; }
         return w;
     };
     auto to_rows = [&](const Raw& w, Row4& L, Row4& D) {
         float a, c;
-        lr_neighbours<HALO>(w.l, w.hl, lane, last_lane, a, c, lsrc, rsrc);
-        L = make_row(w.l, a, c);
-        lr_neighbours<HALO>(w.d, w.hd, lane, last_lane, a, c, lsrc, rsrc);
-        D = make_row(w.d, a, c);
+        const float4 l = widen4(w.l), d = widen4(w.d);
+        lr_neighbours<HALO>(l, (float)w.hl, lane, last_lane, a, c, lsrc, rsrc);
+        L = make_row(l, a, c);
+        lr_neighbours<HALO>(d, (float)w.hd, lane, last_lane, a, c, lsrc, rsrc);
+        D = make_row(d, a, c);
     };
 
     Row4 WL[RB + 2], WD[RB + 2];
@@ -275,34 +276,48 @@ __device__ __forceinline__ void stream_body(const plane_t* __restrict__ inL, con
             queue_tie<3>(tie[3], nq, q, (unsigned)G.qcap, world, r0 + k, colq, upL, miL, dnL, upD, miD, dnD, ol, od);
         }
     };
-    // One block = RB (2) rows: prefetch the two rows the NEXT block needs, compute the two rows of this one from the
-    // four-row window, then drop the prefetched rows into the two window slots that just became free.  The window
-    // is a ring: the block alternates between the slot orders (0,1,2,3) and (2,3,0,1) - written out as two
-    // phases - instead of shifting rows from slot to slot (32 register moves per block: 4 of the 49 VALU
-    // instructions per cell-update of the float32 kernel).
+    // One block = RB (2) rows: issue loads, compute the block's two rows from the four-row window, then drop two
+    // loaded rows into the window slots that just became free.  In the float32-only kernel the loads run TWO
+    // blocks ahead of their use (DEEP: a block loads what the block after next needs and consumes what the
+    // previous block loaded; a binary16 row in flight costs 6 VGPRs, and with one block of slack the kernel was
+    // bound by its bytes in flight - 4 waves x 2 rows x 1 KB per SIMD: C2 0.135 -> 0.122 ms, 64 x 1024^2 -11 %).
+    // The exact kernel is at its 168-VGPR budget (3 waves/SIMD): the extra rows in flight spilled inside the row
+    // loop (+12...+17 % time), so it keeps one block of slack.  Window and load buffers are rings: the block
+    // alternates between the slot orders (0,1,2,3) / (2,3,0,1) and the buffer pairs (A,B) / (B,A) - written out
+    // as two phases - instead of shifting rows from slot to slot (32 register moves per block).
     static_assert(RB == 2, "the ring below is written for two-row blocks");
-    auto block = [&](auto PHc, int kk) {
+    constexpr bool DEEP = !EXACT;
+    Raw rawA[2], rawB[2];
+    if (DEEP) {
+        rawA[0] = load_raw(r0 + 3);                         // rows 3, 4 of the strip: consumed by the first block
+        rawA[1] = load_raw(r0 + 4);
+    }
+    auto block = [&](auto PHc, int kk, Raw (&use)[2], Raw (&fill)[2]) {
         constexpr int PH = decltype(PHc)::value;           // physical slot of the block's first window row
         constexpr int s0 = PH, s1 = (PH + 1) & 3, s2 = (PH + 2) & 3, s3 = (PH + 3) & 3;
-        Raw nx[2];
-        nx[0] = load_raw(r0 + kk + 3);
-        nx[1] = load_raw(r0 + kk + 4);
+        if (DEEP) {
+            fill[0] = load_raw(r0 + kk + 5);                // for the NEXT block (clamped to the strip's halo row)
+            fill[1] = load_raw(r0 + kk + 6);
+        } else {
+            use[0] = load_raw(r0 + kk + 3);                 // consumed at the end of this block
+            use[1] = load_raw(r0 + kk + 4);
+        }
         __builtin_amdgcn_sched_barrier(0);                  // loads first, then the arithmetic
         row_math(WL[s0], WL[s1], WL[s2], WD[s0], WD[s1], WD[s2], kk);
         row_math(WL[s1], WL[s2], WL[s3], WD[s1], WD[s2], WD[s3], kk + 1);
         __builtin_amdgcn_sched_barrier(0);
-        to_rows(nx[0], WL[s0], WD[s0]);                     // rows kk+3, kk+4: window rows 2, 3 of the next block
-        to_rows(nx[1], WL[s1], WD[s1]);
+        to_rows(use[0], WL[s0], WD[s0]);                    // rows kk+3, kk+4: window rows 2, 3 of the next block
+        to_rows(use[1], WL[s1], WD[s1]);
     };
     using PH0 = std::integral_constant<int, 0>;
     using PH2 = std::integral_constant<int, 2>;
     int k = 0;
     for (; k + 4 <= nr; k += 4) {
-        block(PH0{}, k);
-        block(PH2{}, k + 2);
+        block(PH0{}, k, rawA, rawB);
+        block(PH2{}, k + 2, rawB, rawA);
     }
     bool odd_phase = false;
-    if (k + 2 <= nr) { block(PH0{}, k); k += 2; odd_phase = true; }
+    if (k + 2 <= nr) { block(PH0{}, k, rawA, rawB); k += 2; odd_phase = true; }
     if (k < nr) {                                           // one row left, already in the window
         if (odd_phase) row_math(WL[2], WL[3], WL[0], WD[2], WD[3], WD[0], k);
         else row_math(WL[0], WL[1], WL[2], WD[0], WD[1], WD[2], k);
@@ -411,7 +426,7 @@ __device__ __forceinline__ void stream_body(const plane_t* __restrict__ inL, con
 // fix-up path and is planned for 3 waves per SIMD (<= 168 VGPRs; its 48 KB of LDS queues per
 // workgroup allow 3 workgroups per CU as well).
 template <int HALO>
-__global__ __launch_bounds__(256) void step_stream_fast(const plane_t* __restrict__ inL, const plane_t* __restrict__ inD,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void step_stream_fast(const plane_t* __restrict__ inL, const plane_t* __restrict__ inD,
                                                         plane_t* __restrict__ outL, plane_t* __restrict__ outD,
                                                         StripGeom G, PhysF32 P, PhysF64 P64,
                                                         StatsDev* __restrict__ stats,
