@@ -1469,7 +1469,8 @@ int dw_run_episode_mlp(dw_handle* h, int32_t nsteps, const double* L_schedule, c
     auto up = [](size_t v) { return (v + 255) / 256 * 256; };
     const size_t wbytes = sizeof(double) * 1808 * (size_t)n_members;
     const size_t o_w = 0, o_ma = up(o_w + wbytes), o_mb = up(o_ma + sizeof(int) * B), o_r = up(o_mb + sizeof(int) * B);
-    const size_t o_d = up(o_r + sizeof(double) * K * bn), total = up(o_d + K * bn);
+    const size_t o_d = up(o_r + sizeof(double) * K * bn), o_p32 = up(o_d + K * bn), o_ls = up(o_p32 + sizeof(PhysF32) * K);
+    const size_t total = up(o_ls + sizeof(double) * K);
     if (int erc = ensure_ep_buf(h, total)) return erc;
     const double* d_w = reinterpret_cast<const double*>(h->ep_buf + o_w);
     const int* d_ma = member_a ? reinterpret_cast<const int*>(h->ep_buf + o_ma) : nullptr;
@@ -1480,7 +1481,48 @@ int dw_run_episode_mlp(dw_handle* h, int32_t nsteps, const double* L_schedule, c
     HIPCHK(hipMemcpyAsync(h->ep_buf + o_w, params, wbytes, hipMemcpyHostToDevice, h->stream));
     if (member_a) HIPCHK(hipMemcpyAsync(h->ep_buf + o_ma, member_a, sizeof(int) * B, hipMemcpyHostToDevice, h->stream));
     if (member_b) HIPCHK(hipMemcpyAsync(h->ep_buf + o_mb, member_b, sizeof(int) * B, hipMemcpyHostToDevice, h->stream));
-    for (size_t t = 0; t < K; ++t) {
+    // Small worlds with a quantised state and a quantised retained previous state: the rest of the chunk in ONE
+    // launch, worlds in LDS (episode_mlp).  Until then - the first two steps of an episode, whose current /
+    // previous state is the un-quantised upload - and for large worlds: one launch sequence per step.
+    const int Cc = p.height * p.width;
+    const int wpb = Cc <= 256 ? 4 : (Cc <= 1024 ? 2 : 1);
+    const size_t lds = episode_mlp_world_bytes(Cc, N) * wpb;
+    const bool small = Cc <= 4096 && lds <= 160 * 1024 && p.precision != DW_PRECISION_F64 &&
+                       !std::getenv("DW_NO_EPISODE_KERNEL");
+    std::vector<PhysF32> p32;
+    SyncOnExit guard2(h->stream);                             // p32 (filled below) must outlive its upload
+    size_t t = 0;
+    while (t < K) {
+        if (small && cur_quantised(h) && h->stepped && h->unq == OWN_NONE) {
+            const size_t Kr = K - t;
+            p32.resize(Kr);
+            for (size_t i = 0; i < Kr; ++i) p32[i] = derive_f32(p, L_schedule[t + i]);
+            HIPCHK(hipMemcpyAsync(h->ep_buf + o_p32, p32.data(), sizeof(PhysF32) * Kr, hipMemcpyHostToDevice, h->stream));
+            HIPCHK(hipMemcpyAsync(h->ep_buf + o_ls, L_schedule + t, sizeof(double) * Kr, hipMemcpyHostToDevice, h->stream));
+            StatsDev* stats = h->stats2[h->sp];
+            HIPCHK(hipMemsetAsync(stats, 0, sizeof(StatsDev) * (B + 1), h->stream));
+            EpisodeMlpIO io;
+            const int cur = h->cur, prev = 1 - h->cur;
+            io.L = h->L16[cur]; io.D = h->D16[cur]; io.prevL = h->L16[prev]; io.prevD = h->D16[prev];
+            io.idx = h->idx; io.st = h->st;
+            io.P32 = reinterpret_cast<const PhysF32*>(h->ep_buf + o_p32);
+            io.Ls = reinterpret_cast<const double*>(h->ep_buf + o_ls);
+            io.weights = d_w; io.member_a = d_ma; io.member_b = d_mb;
+            io.reward = d_r + t * bn; io.done = d_d + t * bn;
+            io.stats = stats; io.fixups = &stats[B].sum_l;
+            const bool ex = p.precision == DW_PRECISION_EXACT;
+            auto kern = ex ? episode_mlp<true> : episode_mlp<false>;
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds));
+            hipLaunchKernelGGL(kern, dim3((unsigned)((B + wpb - 1) / wpb)), dim3(256), lds, h->stream, io, B, N, p.height,
+                               p.width, wpb, (int)Kr, p.obs_mask, p.agent_gamma, make_f64(p, L_schedule[t]), h->L_last,
+                               (int)split);
+            HIPCHK(hipGetLastError());
+            h->stepped = true;
+            h->L_last = L_schedule[K - 1];
+            t = K;
+            break;
+        }
         int rc = observe_into_scratch(h, L_init, 0);
         if (rc) return rc;
         // both halves in one launch (agents [split, N) read member_b), reward / done written by the grazing
@@ -1492,10 +1534,12 @@ int dw_run_episode_mlp(dw_handle* h, int32_t nsteps, const double* L_schedule, c
         if (rc) return rc;
         rc = launch_forward(h, L_schedule[t]);
         if (rc) return rc;
+        ++t;
     }
     if (reward) HIPCHK(hipMemcpyAsync(reward, d_r, sizeof(double) * K * bn, hipMemcpyDeviceToHost, h->stream));
     if (done) HIPCHK(hipMemcpyAsync(done, d_d, K * bn, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    guard2.disarm();
     guard.disarm();
     return DW_OK;
 }
