@@ -1107,7 +1107,7 @@ def test_fused_fast_trajectory_vs_oracle_tolerance(amd):
     eng.close()
 
 
-@pytest.mark.parametrize("B,H,W", [(3, 256, 256), (1, 70, 320), (2, 64, 1024),
+@pytest.mark.parametrize("B,H,W", [(3, 256, 256), (1, 70, 320), (2, 64, 1024), (1, 200, 1024),
                                    (5, 64, 64), (33, 8, 8), (3, 130, 128), (9, 20, 16),                # packed
                                    (3, 70, 96), (5, 20, 100), (2, 66, 192)])
 def test_fused_exact_trajectory_bit_exact_vs_oracle(amd, monkeypatch, B, H, W):
@@ -1147,6 +1147,7 @@ def test_fused_exact_other_constants_vs_oracle(amd, over, B, H, W):
 
 
 @pytest.mark.parametrize("B,H,W,nsteps,kernel", [(2, 256, 256, 7, None), (1, 70, 320, 6, None), (2, 64, 128, 3, None),
+                                                 (2, 40, 1024, 7, None),      # the four-wave ring: repairs across waves
                                                  (2, 64, 192, 3, None), (5, 64, 64, 6, None), (9, 16, 32, 5, None),
                                                  (3, 50, 100, 5, None), (2, 64, 128, 3, "tiled"),
                                                  (2, 64, 192, 3, "tiled"), (1, 70, 320, 4, "tiled")])

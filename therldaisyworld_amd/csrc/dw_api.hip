@@ -94,6 +94,7 @@ struct dw_handle {
     bool use_stream = false;
     StripGeom sgeom{};
     bool allow_fuse = false;          // wide grids: dw_step_n / dw_run_episode fuse pairs of steps
+    bool fused_ring = false;          // W == 1024: the four waves of a workgroup form a ring over the torus row
     FusedGeom fgeom{};
     int* done_at = nullptr;           // [B]
     int* agents_done_at = nullptr;    // [B][N]
@@ -370,11 +371,14 @@ static void select_kernel(dw_handle* h) {
         f.B = p.batch; f.H = p.height; f.W = p.width;
         f.SR = g.SR;
         f.lpw = g.lpw; f.wpr = g.wpr;
-        f.cols_per_strip = p.width <= 256 ? 256 : 248;
+        // W == 1024: one WORKGROUP per row strip, its four waves side by side (edge columns through LDS) instead of
+        // five overlapped 248-column strips (DW_NO_RING: experiments)
+        h->fused_ring = p.width == 1024 && !std::getenv("DW_NO_RING");
+        f.cols_per_strip = p.width <= 256 ? 256 : (h->fused_ring ? 1024 : 248);
         f.ncs = packable ? 1 : (p.width + f.cols_per_strip - 1) / f.cols_per_strip;
         f.nrs = (p.height + f.SR - 1) / f.SR;
         f.nstrips = (packable ? (p.batch + f.wpr - 1) / f.wpr : p.batch) * f.nrs * f.ncs;
-        f.nwg = (f.nstrips + 3) / 4;
+        f.nwg = h->fused_ring ? f.nstrips : (f.nstrips + 3) / 4;
         f.chunk = (f.nwg + 7) / 8;
         f.qcap = g.qcap;
         f.mcap = mcap;
@@ -545,15 +549,17 @@ static int launch_forward_fused2(dw_handle* h, double L1, double L2, unsigned in
     const int zero_n = (int)(h->stats_bytes / sizeof(unsigned long long));
     const FusedGeom& g = h->fgeom;
     const dim3 grid((unsigned)g.chunk * 8u);
-    const bool rot = p.width == 256, pack = p.width < 256;
+    const bool rot = p.width == 256, pack = p.width < 256, ring = h->fused_ring;
     if (p.precision == DW_PRECISION_EXACT) {
         const FusedExactArgs A{h->L16[in], h->D16[in], h->L16[out], h->D16[out], g, P1, lum_part(P2), zero_me, zero_n,
                                pstats, thr_hi, make_f64(p, L1), L1, L2};
 #define DW_FX(R, P, S) hipLaunchKernelGGL((step_stream_fused2_exact<R, P, S>), grid, dim3(256), 0, h->stream, A)
         if (pstats) {
-            if (pack) DW_FX(true, true, true); else if (rot) DW_FX(true, false, true); else DW_FX(false, false, true);
+            if (pack) DW_FX(kFusedRot, true, true); else if (rot) DW_FX(kFusedRot, false, true);
+            else if (ring) DW_FX(kFusedRing, false, true); else DW_FX(kFusedOvl, false, true);
         } else {
-            if (pack) DW_FX(true, true, false); else if (rot) DW_FX(true, false, false); else DW_FX(false, false, false);
+            if (pack) DW_FX(kFusedRot, true, false); else if (rot) DW_FX(kFusedRot, false, false);
+            else if (ring) DW_FX(kFusedRing, false, false); else DW_FX(kFusedOvl, false, false);
         }
 #undef DW_FX
     } else {
@@ -561,9 +567,11 @@ static int launch_forward_fused2(dw_handle* h, double L1, double L2, unsigned in
     hipLaunchKernelGGL((step_stream_fused2<R, P, S>), grid, dim3(256), 0, h->stream, h->L16[in], h->D16[in],      \
                        h->L16[out], h->D16[out], g, P1, P2, zero_me, zero_n, pstats, thr_hi)
         if (pstats) {
-            if (pack) DW_FF(true, true, true); else if (rot) DW_FF(true, false, true); else DW_FF(false, false, true);
+            if (pack) DW_FF(kFusedRot, true, true); else if (rot) DW_FF(kFusedRot, false, true);
+            else if (ring) DW_FF(kFusedRing, false, true); else DW_FF(kFusedOvl, false, true);
         } else {
-            if (pack) DW_FF(true, true, false); else if (rot) DW_FF(true, false, false); else DW_FF(false, false, false);
+            if (pack) DW_FF(kFusedRot, true, false); else if (rot) DW_FF(kFusedRot, false, false);
+            else if (ring) DW_FF(kFusedRing, false, false); else DW_FF(kFusedOvl, false, false);
         }
 #undef DW_FF
     }

@@ -17,6 +17,10 @@ namespace dw {
 //
 // Horizontal neighbours of step-1 results come from adjacent lanes by DPP like the inputs do.
 //   ROT (W == 256): the wave spans the whole torus row, all 64 lanes produce output.
+//   RING (W == 1024): the FOUR waves of a workgroup span the torus row (wave w owns columns 256 w ... 256 w + 255);
+//                   per row they exchange their edge columns - of the input row and of the step-1 row - through 256
+//                   bytes of LDS with one workgroup barrier, so all 64 lanes of every wave produce output (the
+//                   overlapped strips would need five 248-column strips: 25 % of the lanes redundant).
 //   OVL (other W):  strips overlap by one lane (4 columns) on each side: lanes 0 and 63 load and
 //                   compute step 1 but only lanes 1..62 (248 columns) produce output; no halo loads.
 // Vertically a strip of SR output rows reads SR+4 input rows and computes SR+2 step-1 rows.
@@ -109,7 +113,8 @@ constexpr int kMismatchCap = 64;            // float32 step-1 mismatches per wav
 //   pstats[2*world + 1] number of this world's output row groups (4 cells of a lane) holding a step-2
 //                       value above `thr_hi` that cannot be an artefact of float32 or be undone by the few
 //                       cells patched afterwards - a sound lower bound, see agents_lookahead_patch.
-template <bool ROT, bool EXACT, bool PACK = false, bool STATS = false, typename TI = plane_t, typename TO = plane_t>
+enum { kFusedOvl = 0, kFusedRot = 1, kFusedRing = 2 };
+template <int MODE, bool EXACT, bool PACK = false, bool STATS = false, typename TI = plane_t, typename TO = plane_t>
 __device__ __forceinline__ void fused2_body(const TI* __restrict__ inL, const TI* __restrict__ inD,
                                             TO* __restrict__ outL, TO* __restrict__ outD, const FusedGeom& G,
                                             const PhysF32& P1, const PhysF32& P2, const PhysF64& P64,
@@ -123,6 +128,9 @@ __device__ __forceinline__ void fused2_body(const TI* __restrict__ inL, const TI
 #define DW_FUSED_LAG 1
 #endif
     constexpr bool LAG = DW_FUSED_LAG != 0;
+    constexpr bool ROT = MODE == kFusedRot, RING = MODE == kFusedRing;
+    static_assert(!RING || (LAG && !PACK), "the ring exchange is written for the lagged loop of un-packed worlds");
+    __shared__ float s_edge[RING ? 2 * 4 * 8 : 1];               // RING: [parity][wave][.w of lane 63 x4 | .x of lane 0 x4]
     __shared__ uint4 s_queue[EXACT ? 4 * kWaveQueueCap * 3 : 1];
     __shared__ unsigned int s_mm[EXACT ? 4 * kMismatchCap : 1];
     const int bid = blockIdx.x;
@@ -131,8 +139,9 @@ __device__ __forceinline__ void fused2_body(const TI* __restrict__ inL, const TI
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
     if (wg == 0)
         for (int i = tid; i < zero_n; i += 256) zero_me[i] = 0ull;
-    const int s = __builtin_amdgcn_readfirstlane(wg * 4 + wv);   // wave-uniform: row addressing goes to the scalar unit
-    if (s >= G.nstrips) return;
+    // RING: the workgroup is the strip (all four waves stay: they meet at a barrier every row)
+    const int s = RING ? wg : __builtin_amdgcn_readfirstlane(wg * 4 + wv);   // wave-uniform: row addressing on the scalar unit
+    if (!RING && s >= G.nstrips) return;
     uint4* q = s_queue + (EXACT ? wv * kWaveQueueCap * 3 : 0);
     unsigned int* mm = s_mm + (EXACT ? wv * kMismatchCap : 0);
     const int spw = G.nrs * G.ncs;
@@ -149,16 +158,16 @@ __device__ __forceinline__ void fused2_body(const TI* __restrict__ inL, const TI
         return (size_t)(PACK ? min(b * G.wpr + min((lc >> 2) / G.lpw, G.wpr - 1), G.B - 1) : b) * G.H * G.W;
     };
     const size_t woff = world_off(4 * lane);
-    const int c00 = ROT ? 0 : cs * 248 - 4;                     // grid column of local column 0 (may be -4)
+    const int c00 = ROT ? 0 : (RING ? 256 * __builtin_amdgcn_readfirstlane(wv) : cs * 248 - 4);   // grid column of local column 0 (OVL: may be -4)
     int col = PACK ? 4 * pj : c00 + 4 * lane;
     col = col < 0 ? col + G.W : col;
     col = col >= G.W ? col - G.W : col;                         // W >= 256 > 252: one wrap suffices
     const bool writes = PACK ? (pw < G.wpr && b * G.wpr + pw < G.B)
-                             : (ROT ? true : (lane >= 1 && lane <= 62 && cs * 248 + 4 * (lane - 1) < G.W));
+                             : ((ROT || RING) ? true : (lane >= 1 && lane <= 62 && cs * 248 + 4 * (lane - 1) < G.W));
     // which of my four step-1 cells feed an output cell of this wave (exact mode: only their ties matter)
     bool need1[4] = {true, true, true, true};
     if (PACK) { need1[0] = need1[1] = need1[2] = need1[3] = writes; }
-    if (EXACT && !ROT) {
+    if (EXACT && !ROT && !RING) {
         const bool wl = __builtin_amdgcn_update_dpp(0, writes ? 1 : 0, kDppWaveShr1, 0xf, 0xf, false) != 0;
         const bool wr = __builtin_amdgcn_update_dpp(0, writes ? 1 : 0, kDppWaveShl1, 0xf, 0xf, false) != 0;
         need1[0] = writes || wl;
@@ -190,6 +199,30 @@ __device__ __forceinline__ void fused2_body(const TI* __restrict__ inL, const TI
         L = make_row(l, a, c);
         nbrs(d, a, c);
         D = make_row(d, a, c);
+    };
+    // RING: n (<= 4) rows of a plane at once -> Row4s, the neighbours of lanes 0 / 63 from the adjacent waves
+    int ring_par = 0;
+    auto rows_ring = [&](const float4* v, Row4* out, auto NC) {
+        constexpr int n = decltype(NC)::value;
+        float* mine = s_edge + (ring_par * 4 + wv) * 8;
+        if (lane == 63) {
+#pragma unroll
+            for (int i = 0; i < n; ++i) mine[i] = v[i].w;
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < n; ++i) mine[4 + i] = v[i].x;
+        }
+        __syncthreads();                                        // one barrier per exchange; the parity flip makes the
+        const float* lw = s_edge + (ring_par * 4 + ((wv + 3) & 3)) * 8;       // next exchange write the other half
+        const float* rw = s_edge + (ring_par * 4 + ((wv + 1) & 3)) * 8 + 4;
+#pragma unroll
+        for (int i = 0; i < n; ++i) {
+            const float a = dpp_mov<kDppWaveShr1>(lw[i], v[i].w);   // lane 0 keeps `old` = the left wave's last column
+            const float c = dpp_mov<kDppWaveShl1>(rw[i], v[i].x);   // lane 63 keeps the right wave's first column
+            out[i] = make_row(v[i], a, c);
+        }
+        ring_par ^= 1;
     };
     unsigned int nq = 0;                                        // queued entries of this wave (uniform)
     float st_m1 = 0.f;                                          // STATS accumulators of this lane
@@ -252,9 +285,18 @@ __device__ __forceinline__ void fused2_body(const TI* __restrict__ inL, const TI
     Row4 IL[3], ID[3], SL[3], SD[3];
     {
         const RawIn p0 = load_raw(r0 - 2), p1 = load_raw(r0 - 1), p2 = load_raw(r0);
-        to_rows4(widen4(p0.l), widen4(p0.d), IL[0], ID[0]);
-        to_rows4(widen4(p1.l), widen4(p1.d), IL[1], ID[1]);
-        to_rows4(widen4(p2.l), widen4(p2.d), IL[2], ID[2]);
+        if constexpr (RING) {
+            const float4 va[4] = {widen4(p0.l), widen4(p0.d), widen4(p1.l), widen4(p1.d)};
+            const float4 vb[2] = {widen4(p2.l), widen4(p2.d)};
+            Row4 oa[4], ob[2];
+            rows_ring(va, oa, std::integral_constant<int, 4>{});
+            rows_ring(vb, ob, std::integral_constant<int, 2>{});
+            IL[0] = oa[0]; ID[0] = oa[1]; IL[1] = oa[2]; ID[1] = oa[3]; IL[2] = ob[0]; ID[2] = ob[1];
+        } else {
+            to_rows4(widen4(p0.l), widen4(p0.d), IL[0], ID[0]);
+            to_rows4(widen4(p1.l), widen4(p1.d), IL[1], ID[1]);
+            to_rows4(widen4(p2.l), widen4(p2.d), IL[2], ID[2]);
+        }
     }
     using U0 = std::integral_constant<int, 0>;
     using U1 = std::integral_constant<int, 1>;
@@ -294,9 +336,18 @@ __device__ __forceinline__ void fused2_body(const TI* __restrict__ inL, const TI
             if (do1) {
                 row_queue(IL[(u + 2) % 3], IL[u], IL[(u + 1) % 3], ID[(u + 2) % 3], ID[u], ID[(u + 1) % 3], l1, d1, tie1, 1, j);
                 if (STATS && writes && j >= 2 && j <= nr + 1) st_m1 = fmaxf(st_m1, sm1);   // step-1 rows of MY output cells
-                to_rows4(make_float4(l1[0], l1[1], l1[2], l1[3]), make_float4(d1[0], d1[1], d1[2], d1[3]), SL[u], SD[u]);
-                __builtin_amdgcn_sched_barrier(0);
-                to_rows4(widen4(nx.l), widen4(nx.d), IL[(u + 2) % 3], ID[(u + 2) % 3]);   // input row j+2 replaces input row j-1
+                if constexpr (RING) {                               // both new rows in ONE exchange (one barrier per iteration)
+                    const float4 v[4] = {make_float4(l1[0], l1[1], l1[2], l1[3]), make_float4(d1[0], d1[1], d1[2], d1[3]),
+                                         widen4(nx.l), widen4(nx.d)};
+                    Row4 o[4];
+                    rows_ring(v, o, std::integral_constant<int, 4>{});
+                    SL[u] = o[0]; SD[u] = o[1];
+                    IL[(u + 2) % 3] = o[2]; ID[(u + 2) % 3] = o[3];
+                } else {
+                    to_rows4(make_float4(l1[0], l1[1], l1[2], l1[3]), make_float4(d1[0], d1[1], d1[2], d1[3]), SL[u], SD[u]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    to_rows4(widen4(nx.l), widen4(nx.d), IL[(u + 2) % 3], ID[(u + 2) % 3]);   // input row j+2 replaces input row j-1
+                }
             }
         };
         using Yes = std::true_type;
@@ -382,13 +433,18 @@ __device__ __forceinline__ void fused2_body(const TI* __restrict__ inL, const TI
         auto is_output = [&](int lrow, int lc) -> bool {
             if (lrow < 2 || lrow > nr + 1) return false;
             if (PACK) return (lc >> 2) / G.lpw < G.wpr && b * G.wpr + (lc >> 2) / G.lpw < G.B;
-            if (ROT) return true;
+            if (ROT || RING) return true;                        // RING: also the two columns beside the wave's own
             const int ln = lc >> 2;
             return lc >= 4 && lc < 252 && cs * 248 + 4 * (ln - 1) < G.W;
         };
         unsigned int nmm = 0;
         bool redo = nq > (unsigned)G.qcap;
-        if (nq) wait_row_stores_before_patching();              // wave-uniform; F2 / F3 / the fallback patch stored rows
+        // RING: a mismatch of a step-1 cell in the wave's first / last column also feeds output cells of the ADJACENT
+        // wave, and this wave repairs them (F3 / the fallback below): every row store of the workgroup must have
+        // completed before any patch store, and every F2 patch (which may rest on a neighbour's mismatched value)
+        // before any F3 patch - two workgroup barriers, each behind a wait for the wave's own stores.
+        if (RING || nq) wait_row_stores_before_patching();      // wave-uniform; F2 / F3 / the fallback patch stored rows
+        if (RING) __syncthreads();
         if (!redo) {
             // F1 + F2 in one sweep over the queue (the entries differ only in the luminosity of their
             // float64 re-evaluation): a step-1 entry whose float32 value was wrong goes to the mismatch
@@ -433,6 +489,10 @@ __device__ __forceinline__ void fused2_body(const TI* __restrict__ inL, const TI
                 nmm += (unsigned)__popcll(mask);
             }
             redo = nmm > (unsigned)G.mcap;
+        }
+        if (RING) {
+            wait_row_stores_before_patching();
+            __syncthreads();
         }
         if (!redo) {
             // F3: everything that depends on a step-1 mismatch, entirely in float64 from the inputs.  Two
@@ -493,9 +553,10 @@ __device__ __forceinline__ void fused2_body(const TI* __restrict__ inL, const TI
             }
         } else {
             // overflow fallback: every output cell of the strip, two float64 steps from the inputs
-            const int ncol = ROT ? 256 : 248;
+            // (RING: plus the column on either side, whose step-2 values depend on this wave's - unverified - step-1 edge)
+            const int ncol = ROT ? 256 : (RING ? 258 : 248);
             for (int i = lane; i < nr * ncol; i += 64) {
-                const int lrow = 2 + i / ncol, lc = (ROT ? 0 : 4) + i % ncol;
+                const int lrow = 2 + i / ncol, lc = (ROT ? 0 : (RING ? -1 : 4)) + i % ncol;
                 if (!is_output(lrow, lc)) continue;
                 int gr, gc;
                 size_t wo;
@@ -557,7 +618,7 @@ __device__ __forceinline__ void fused2_body(const TI* __restrict__ inL, const TI
 #ifndef DW_FUSED_FAST_WAVES
 #define DW_FUSED_FAST_WAVES 4
 #endif
-template <bool ROT, bool PACK = false, bool STATS = false>
+template <int MODE, bool PACK = false, bool STATS = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DW_FUSED_FAST_WAVES, DW_FUSED_FAST_WAVES)))
 void step_stream_fused2(const plane_t* __restrict__ inL, const plane_t* __restrict__ inD,
                                                           plane_t* __restrict__ outL, plane_t* __restrict__ outD,
@@ -566,7 +627,7 @@ void step_stream_fused2(const plane_t* __restrict__ inL, const plane_t* __restri
                                                           unsigned int* __restrict__ pstats, float thr_hi) {
     const PhysF64 dummy{};
     const double zero = 0.0;
-    fused2_body<ROT, false, PACK, STATS>(inL, inD, outL, outD, G, P1, P2, dummy, zero, zero, zero_me, zero_n, pstats, thr_hi);
+    fused2_body<MODE, false, PACK, STATS>(inL, inD, outL, outD, G, P1, P2, dummy, zero, zero, zero_me, zero_n, pstats, thr_hi);
 }
 
 // Waves per SIMD of the exact kernels: the plain variants fit 3 waves/SIMD (153-155 VGPRs); the packed and
@@ -586,13 +647,13 @@ struct FusedExactArgs {
     PhysF64 P64; double La; double Lb;                            // cold (see kernarg_struct)
 };
 
-template <bool ROT, bool PACK = false, bool STATS = false>
+template <int MODE, bool PACK = false, bool STATS = false>
 __global__ __launch_bounds__(256)
 __attribute__((amdgpu_waves_per_eu(fused_exact_waves<PACK, STATS>(), fused_exact_waves<PACK, STATS>())))
 void step_stream_fused2_exact(FusedExactArgs A) {
     const FusedExactArgs& cold = kernarg_struct<FusedExactArgs>();
     const PhysF32 P2 = with_lum(A.P1, A.lum2);
-    fused2_body<ROT, true, PACK, STATS>(A.inL, A.inD, A.outL, A.outD, A.G, A.P1, P2, cold.P64, cold.La, cold.Lb, A.zero_me,
+    fused2_body<MODE, true, PACK, STATS>(A.inL, A.inD, A.outL, A.outD, A.G, A.P1, P2, cold.P64, cold.La, cold.Lb, A.zero_me,
                                         A.zero_n, A.pstats, A.thr_hi);
 }
 
