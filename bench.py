@@ -351,7 +351,8 @@ def main():
         achieved = alg / (launch_ms * 1e-3) / 1e9
         tr, tr_file = load_profile("traffic", m["workload"], m["precision"])
         va, va_file = load_profile("valu", m["workload"], m["precision"])
-        traffic = tr.get("hbm_bytes_per_launch") if tr and spl == 2 else None
+        # the committed profile may be of another world count: scale its bytes per cell-update to this run's launch
+        traffic = tr["hbm_bytes_per_cell_update"] * m["cells"] * spl if tr and spl == 2 else None
         measured = traffic / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if traffic else None
         valu = None
         if va and spl == 2:
