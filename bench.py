@@ -243,7 +243,12 @@ def main():
             eng = None
             try:
                 eng = amd.Engine(p)
-                eng.init_random(args.seed)
+                try:
+                    eng.init_random(args.seed)              # un-quantised like the reference's initialize_grid
+                except amd.DaisyHipError as e:
+                    if e.code != _ffi.DW_ENOMEM:
+                        raise
+                    eng.init_random(args.seed, quantised=True)   # no room for the float32 staging: rounded draw
                 return eng, B
             except amd.DaisyHipError as e:
                 if eng is not None:

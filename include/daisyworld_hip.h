@@ -168,6 +168,12 @@ int dw_download_agents(dw_handle* h, int32_t* indices, double* states);
  * uniform cells with state 1.  Used for the large synthetic configurations. */
 int dw_init_random(dw_handle* h, uint64_t seed);
 
+/* The same draw with every cover rounded to three decimals (what np.round(., 3) would make of it), written
+ * straight into the binary16 planes: a QUANTISED synthetic state.  Needs no float32 staging (dw_init_random holds
+ * the un-quantised state in 8 bytes per cell until the second step) and no float64 first step; for ensembles that
+ * fill the device.  Same worlds as dw_init_random up to that rounding (same keys). */
+int dw_init_random_quantised(dw_handle* h, uint64_t seed);
+
 /* Download light/dark cover of the current or previous state in natural units, [B][H][W] float64
  * (either pointer may be NULL). */
 int dw_download_planes(dw_handle* h, int which, double* light, double* dark);

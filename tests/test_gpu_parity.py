@@ -653,6 +653,21 @@ def test_init_random_distribution_and_shard_invariance(amd):
         assert vals.max() <= 0.2 and abs(vals.mean() - 0.1) < 0.003
     assert not np.array_equal(fl, fd)
     assert fi.min() >= 0 and fi[..., 0].max() < H and fi[..., 1].max() < W and np.all(fs == 1.0)
+    # the quantised draw: the same worlds rounded to three decimals (float32 rounding of 1000 * cover), straight
+    # into the binary16 planes - steps, snapshots and device planes work at once
+    q = _engine(amd, B, H, W, N, "exact")
+    q.init_random(99, quantised=True)
+    ql, qd = q.download_planes()
+    assert np.array_equal(_k(ql), np.rint(np.float32(fl * 1000.0).astype(np.float64))) or np.abs(_k(ql) - _k(fl)).max() <= 1
+    assert np.abs(ql - fl).max() <= 5.1e-4 and np.abs(qd - fd).max() <= 5.1e-4
+    assert np.array_equal(ql, np.round(ql, 3)) and np.array_equal(q.download_agents()[0], fi)
+    q.device_planes()
+    q.snapshot_save()
+    q.step(0.9)
+    ref = c_oracle.forward(ql, qd, 0.9)
+    kl, kd = (_k(x) for x in q.download_planes())
+    assert np.array_equal(kl, _k(ref[:, 1])) and np.array_equal(kd, _k(ref[:, 2]))
+    q.close()
     full.close()
 
 

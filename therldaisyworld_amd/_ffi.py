@@ -64,6 +64,7 @@ SIGNATURES = {
     "dw_upload_agents": (C.c_int, [_vp, _pi, _pd]),
     "dw_download_agents": (C.c_int, [_vp, _pi, _pd]),
     "dw_init_random": (C.c_int, [_vp, _u64]),
+    "dw_init_random_quantised": (C.c_int, [_vp, _u64]),
     "dw_download_planes": (C.c_int, [_vp, C.c_int, _pd, _pd]),
     "dw_download_grid": (C.c_int, [_vp, _dbl, _pd]),
     "dw_download_caches": (C.c_int, [_vp, _dbl, _pd, _pd, _pd, _pd]),

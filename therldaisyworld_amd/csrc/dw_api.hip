@@ -911,6 +911,31 @@ int dw_init_random(dw_handle* h, uint64_t seed) {
     return refresh_stats(h);
 }
 
+int dw_init_random_quantised(dw_handle* h, uint64_t seed) {
+    NEED(h, DW_EINVAL, "null handle");
+    const dw_params& p = h->prm;
+    HIPCHK(hipSetDevice(p.device));
+    const dim3 g((unsigned)((p.height * p.width + 255) / 256), (unsigned)p.batch);
+    hipLaunchKernelGGL(init_random_cells_q, g, dim3(256), 0, h->stream, h->L16[h->cur], h->D16[h->cur], p.height,
+                       p.width, (long long)p.world_offset, (unsigned long long)seed, (float)p.light_proportion,
+                       (float)p.dark_proportion, (float)p.initial_al, (float)p.initial_ad);
+    HIPCHK(hipGetLastError());
+    if (p.n_agents) {
+        const int bn = p.batch * p.n_agents;
+        hipLaunchKernelGGL(init_random_agents, dim3((bn + 255) / 256), dim3(256), 0, h->stream, h->idx, h->st,
+                           p.batch, p.n_agents, p.height, p.width, (long long)p.world_offset,
+                           (unsigned long long)seed);
+        HIPCHK(hipGetLastError());
+    }
+    h->have_agents = true;
+    h->unq = OWN_NONE;
+    h->have_state = true;
+    h->stepped = false;
+    h->snap_valid = false;
+    release_unquantised(h);
+    return refresh_stats(h);
+}
+
 int dw_download_planes(dw_handle* h, int which, double* light, double* dark) {
     NEED(h, DW_EINVAL, "null handle");
     NEED(h->have_state, DW_ESTATE, "no state");

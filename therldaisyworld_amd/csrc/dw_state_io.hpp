@@ -157,6 +157,26 @@ __global__ __launch_bounds__(256) void init_random_cells(float* __restrict__ L, 
     D[o] = d * 1000.f;
 }
 
+// the same draw rounded to three decimals (np.round(., 3): rint of the per-mille value), straight into binary16
+// planes: a quantised synthetic state that needs no float32 staging (dw_init_random_quantised)
+__global__ __launch_bounds__(256) void init_random_cells_q(plane_t* __restrict__ L, plane_t* __restrict__ D,
+                                                           int H, int W, long long world_offset,
+                                                           unsigned long long seed, float light_prop,
+                                                           float dark_prop, float ial, float iad) {
+    const int b = blockIdx.y;
+    const int cell = blockIdx.x * 256 + threadIdx.x;
+    if (cell >= H * W) return;
+    const unsigned long long world = (unsigned long long)(world_offset + b);
+    uint32_t r[4];
+    philox4x32_10((uint32_t)cell, 0u, (uint32_t)world, (uint32_t)(world >> 32), (uint32_t)seed,
+                  (uint32_t)(seed >> 32), r);
+    const float d = (u01(r[0]) < dark_prop) ? iad * u01(r[1]) : 0.f;
+    const float l = (u01(r[2]) < light_prop) ? ial * u01(r[3]) : 0.f;
+    const size_t o = (size_t)b * H * W + cell;
+    L[o] = (plane_t)__builtin_rintf(l * 1000.f);
+    D[o] = (plane_t)__builtin_rintf(d * 1000.f);
+}
+
 __global__ void init_random_agents(int* __restrict__ idx, double* __restrict__ st, int B, int N, int H,
                                    int W, long long world_offset, unsigned long long seed) {
     const int an = blockIdx.x * blockDim.x + threadIdx.x;

@@ -91,8 +91,11 @@ class Engine:
         self._check(self._lib.dw_download_agents(self._h, _ffi.ptr_i(idx), _ffi.ptr_d(st)))
         return idx, st
 
-    def init_random(self, seed: int):
-        self._check(self._lib.dw_init_random(self._h, C.c_uint64(seed & (2 ** 64 - 1))))
+    def init_random(self, seed: int, quantised: bool = False):
+        """Device Philox initial state; quantised=True: covers rounded to 3 decimals, straight into the binary16
+        planes (no float32 staging of the un-quantised state, no float64 first step)."""
+        fn = self._lib.dw_init_random_quantised if quantised else self._lib.dw_init_random
+        self._check(fn(self._h, C.c_uint64(seed & (2 ** 64 - 1))))
 
     def download_planes(self, which=_ffi.STATE_CURRENT):
         light = np.empty((self.B, self.H, self.W))
