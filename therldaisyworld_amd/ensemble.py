@@ -31,8 +31,9 @@ def shard_worlds(total_worlds: int, rank: int, world_size: int):
     return offset, count
 
 
-def init_process_group(backend: str | None = None):
-    """Initialise torch.distributed from the torchrun environment (no-op for a single process)."""
+def init_process_group(backend: str | None = None, device: int | None = None):
+    """Initialise torch.distributed from the torchrun environment (no-op for a single process).  `device`: the
+    GPU of this rank when it is not LOCAL_RANK (rehearsals with several ranks on one GPU)."""
     import torch
     import torch.distributed as dist
     rank, local_rank, world = rank_info()
@@ -42,7 +43,7 @@ def init_process_group(backend: str | None = None):
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
-            torch.cuda.set_device(local_rank)
+            torch.cuda.set_device(local_rank if device is None else device)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return dist
 
