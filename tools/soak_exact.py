@@ -20,7 +20,7 @@ steps = int(sys.argv[3]) if len(sys.argv) > 3 else 512
 nchk = int(sys.argv[4]) if len(sys.argv) > 4 else 4
 seed = int(sys.argv[5]) if len(sys.argv) > 5 else 7
 c_oracle.build()
-c_oracle.set_threads(min(c_oracle.max_threads(), len(os.sched_getaffinity(0))))
+c_oracle.set_threads(min(c_oracle.max_threads(), c_oracle.usable_cpus()))
 p = amd.default_params(B, G, G, 0)
 p.precision = _ffi.PRECISION["exact"]
 eng = amd.Engine(p)
