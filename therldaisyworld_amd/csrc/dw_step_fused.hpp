@@ -202,7 +202,7 @@ __device__ __forceinline__ void fused2_body(const TI* __restrict__ inL, const TI
     };
     // RING: n (<= 4) rows of a plane at once -> Row4s, the neighbours of lanes 0 / 63 from the adjacent waves
     int ring_par = 0;
-    auto rows_ring = [&](const float4* v, Row4* out, auto NC) {
+    auto rows_ring = [&](const float4* v, Row4* const* out, auto NC) {
         constexpr int n = decltype(NC)::value;
         float* mine = s_edge + (ring_par * 4 + wv) * 8;
         if (lane == 63) {
@@ -220,7 +220,7 @@ __device__ __forceinline__ void fused2_body(const TI* __restrict__ inL, const TI
         for (int i = 0; i < n; ++i) {
             const float a = dpp_mov<kDppWaveShr1>(lw[i], v[i].w);   // lane 0 keeps `old` = the left wave's last column
             const float c = dpp_mov<kDppWaveShl1>(rw[i], v[i].x);   // lane 63 keeps the right wave's first column
-            out[i] = make_row(v[i], a, c);
+            *out[i] = make_row(v[i], a, c);                       // straight into its window slot
         }
         ring_par ^= 1;
     };
@@ -288,10 +288,10 @@ __device__ __forceinline__ void fused2_body(const TI* __restrict__ inL, const TI
         if constexpr (RING) {
             const float4 va[4] = {widen4(p0.l), widen4(p0.d), widen4(p1.l), widen4(p1.d)};
             const float4 vb[2] = {widen4(p2.l), widen4(p2.d)};
-            Row4 oa[4], ob[2];
+            Row4* const oa[4] = {&IL[0], &ID[0], &IL[1], &ID[1]};
+            Row4* const ob[2] = {&IL[2], &ID[2]};
             rows_ring(va, oa, std::integral_constant<int, 4>{});
             rows_ring(vb, ob, std::integral_constant<int, 2>{});
-            IL[0] = oa[0]; ID[0] = oa[1]; IL[1] = oa[2]; ID[1] = oa[3]; IL[2] = ob[0]; ID[2] = ob[1];
         } else {
             to_rows4(widen4(p0.l), widen4(p0.d), IL[0], ID[0]);
             to_rows4(widen4(p1.l), widen4(p1.d), IL[1], ID[1]);
@@ -339,10 +339,8 @@ __device__ __forceinline__ void fused2_body(const TI* __restrict__ inL, const TI
                 if constexpr (RING) {                               // both new rows in ONE exchange (one barrier per iteration)
                     const float4 v[4] = {make_float4(l1[0], l1[1], l1[2], l1[3]), make_float4(d1[0], d1[1], d1[2], d1[3]),
                                          widen4(nx.l), widen4(nx.d)};
-                    Row4 o[4];
+                    Row4* const o[4] = {&SL[u], &SD[u], &IL[(u + 2) % 3], &ID[(u + 2) % 3]};
                     rows_ring(v, o, std::integral_constant<int, 4>{});
-                    SL[u] = o[0]; SD[u] = o[1];
-                    IL[(u + 2) % 3] = o[2]; ID[(u + 2) % 3] = o[3];
                 } else {
                     to_rows4(make_float4(l1[0], l1[1], l1[2], l1[3]), make_float4(d1[0], d1[1], d1[2], d1[3]), SL[u], SD[u]);
                     __builtin_amdgcn_sched_barrier(0);
