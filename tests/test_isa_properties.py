@@ -1,0 +1,81 @@
+"""Properties of the gfx950 code the performance claims rest on, checked on the assembly hipcc emits (no GPU needed;
+one extra compilation of csrc/dw_api.hip with --save-temps, ~25 s):
+
+  * no MFMA anywhere (north star: this path is a stencil, not a dense contraction);
+  * the step kernels' hot loops hold no scratch (spill) traffic;
+  * register budgets: every float32 step kernel fits 128 VGPRs (4 waves/SIMD), every exact one 168 (3 waves/SIMD) -
+    except the packed / STATS exact fused variants, planned for 2;
+  * the hot loops are made of packed float32 arithmetic (v_pk_*), 6 transcendentals per cell-evaluation.
+"""
+import os
+import re
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+@pytest.fixture(scope="module")
+def asm():
+    import shutil
+    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("hipcc not available")
+    import isa_report
+    return open(isa_report.build([])).read()
+
+
+def _kernels(text):
+    """name -> (info dict, body text) for every kernel of the module."""
+    out = {}
+    for name in re.findall(r"\.amdhsa_kernel (\S+)\n", text):
+        m = re.search(r"\n" + re.escape(name) + r":[^\n]*\n(.*?)\n\.Lfunc_end", text, re.S)
+        info = re.search(re.escape(name) + r":.*?; Kernel info:(.*?)(?=\n\t\.(?:text|section)|\Z)", text, re.S)
+        if not (m and info):
+            continue
+        vals = {k: int(v) for k, v in re.findall(r"; (\w+)\s*[:=] (\d+)", info.group(1))}
+        out[name] = (vals, m.group(1))
+    return out
+
+
+def _hot_loop(body):
+    lines = body.split("\n")
+    labels = {m.group(1): i for i, ln in enumerate(lines) for m in [re.match(r"(\.LBB\S+):", ln)] if m}
+    best, best_pk = None, -1
+    for i, ln in enumerate(lines):
+        m = re.match(r"\ts_c?branch\S* (\.LBB\S+)", ln)
+        if m and m.group(1) in labels and labels[m.group(1)] < i:
+            npk = sum(1 for x in lines[labels[m.group(1)]:i + 1] if x.startswith("\tv_pk_"))
+            if npk > best_pk:
+                best, best_pk = (labels[m.group(1)], i), npk
+    return lines[best[0]:best[1] + 1] if best else []
+
+
+def test_no_mfma_and_no_cuda_shims(asm):
+    assert not re.search(r"\tv_mfma", asm)
+    assert not re.search(r"\tv_smfma|\tv_wmma", asm)
+
+
+def test_step_kernels_register_budgets_and_clean_hot_loops(asm):
+    ks = _kernels(asm)
+    step = {n: v for n, v in ks.items() if "step_stream" in n}
+    assert len(step) >= 20
+    for name, (info, body) in step.items():
+        exact = "exact" in name
+        fused = "fused2" in name
+        loop = _hot_loop(body)
+        assert loop, name
+        assert not any(ln.startswith("\tscratch_") for ln in loop), f"{name}: scratch traffic inside the row loop"
+        npk = sum(1 for ln in loop if ln.startswith("\tv_pk_"))
+        ntr = sum(1 for ln in loop if re.match(r"\tv_(sqrt|rcp)_f32", ln))
+        assert npk >= 150 and ntr >= 48, (name, npk, ntr)     # the map is packed float32 + 6 transcendentals per cell
+        if not exact:
+            ring_stats = "fused2ILi2ELb0ELb1E" in name      # the ring variant with per-step world flags: 3 waves/SIMD
+            assert info["Occupancy"] >= (3 if ring_stats else 4), (name, info["NumVgprs"])
+        else:
+            plain_fused = any(f"fused2_exactILi{m}ELb0ELb0E" in name for m in (0, 1, 2))   # not packed, no STATS
+            if "step_stream_exactILi" in name or plain_fused:
+                assert info["NumVgprs"] <= 168 and info["Occupancy"] >= 3, (name, info["NumVgprs"])
+            else:
+                assert info["NumVgprs"] <= 256 and info["Occupancy"] >= 2, (name, info["NumVgprs"])
