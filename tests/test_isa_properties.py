@@ -71,8 +71,10 @@ def test_step_kernels_register_budgets_and_clean_hot_loops(asm):
         ntr = sum(1 for ln in loop if re.match(r"\tv_(sqrt|rcp)_f32", ln))
         assert npk >= 150 and ntr >= 48, (name, npk, ntr)     # the map is packed float32 + 6 transcendentals per cell
         if not exact:
-            ring_stats = "fused2ILi2ELb0ELb1E" in name      # the ring variant with per-step world flags: 3 waves/SIMD
-            assert info["Occupancy"] >= (3 if ring_stats else 4), (name, info["NumVgprs"])
+            # 3 waves/SIMD by design: the ring variant with per-step world flags and the packed fused variants (no
+            # measurable difference to 4 on 65536 x 16^2 ... 2048 x 128^2, and no scratch at all)
+            three = "fused2ILi2ELb0ELb1E" in name or "fused2ILi1ELb1E" in name
+            assert info["Occupancy"] >= (3 if three else 4), (name, info["NumVgprs"])
         else:
             plain_fused = any(f"fused2_exactILi{m}ELb0ELb0E" in name for m in (0, 1, 2))   # not packed, no STATS
             if "step_stream_exactILi" in name or plain_fused:

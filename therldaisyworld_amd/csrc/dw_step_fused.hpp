@@ -616,11 +616,13 @@ __device__ __forceinline__ void fused2_body(const TI* __restrict__ inL, const TI
 #ifndef DW_FUSED_FAST_WAVES
 #define DW_FUSED_FAST_WAVES 4
 #endif
-// (the ring variant that also reduces the per-step world flags would spill inside its row loop at 128: it keeps 3)
-template <int MODE, bool STATS>
-constexpr int fused_fast_waves() { return (MODE == kFusedRing && STATS) ? 3 : DW_FUSED_FAST_WAVES; }
+// (the ring variant that also reduces the per-step world flags would spill inside its row loop at 128: it keeps 3;
+// so do the packed variants - 130-134 VGPRs without any scratch, and no measurable difference to 4 waves)
+template <int MODE, bool PACK, bool STATS>
+constexpr int fused_fast_waves() { return ((MODE == kFusedRing && STATS) || PACK) ? 3 : DW_FUSED_FAST_WAVES; }
 template <int MODE, bool PACK = false, bool STATS = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(fused_fast_waves<MODE, STATS>(), fused_fast_waves<MODE, STATS>())))
+__global__ __launch_bounds__(256)
+__attribute__((amdgpu_waves_per_eu(fused_fast_waves<MODE, PACK, STATS>(), fused_fast_waves<MODE, PACK, STATS>())))
 void step_stream_fused2(const plane_t* __restrict__ inL, const plane_t* __restrict__ inD,
                                                           plane_t* __restrict__ outL, plane_t* __restrict__ outD,
                                                           FusedGeom G, PhysF32 P1, PhysF32 P2,
