@@ -293,7 +293,10 @@ int dw_policy_mlp_population(dw_handle* h, const double* params, int32_t n_membe
  * to the device once; per step: observations (ref get_obs :246-263), MLP.get_action (agents/mlp.py:97-116),
  * update_agents, forward; the step's reward = state * (state > 0) and done = reward < 0.1 (ref :486-492)
  * come back as [K][B][N].  member_a / member_b may be NULL when n_members == 1.  L_init: luminosity of the
- * observations' temperature channels if no step has been taken yet. */
+ * observations' temperature channels if no step has been taken yet.  Worlds of H*W <= 4096 cells run the chunk as
+ * ONE launch with the worlds resident in LDS (csrc/dw_episode.hpp: episode_mlp) once the state and the retained
+ * previous state are quantised - i.e. from the third step of an episode on; larger worlds and the first two
+ * steps take one launch sequence per step.  Same results either way. */
 int dw_run_episode_mlp(dw_handle* h, int32_t nsteps, const double* L_schedule, const double* params /* [n_members][1808] */,
                        int32_t n_members, const int32_t* member_a /* [B] */, const int32_t* member_b /* [B] */,
                        int32_t split, double L_init, double* reward /* [K][B][N] */, uint8_t* done /* [K][B][N] */);
