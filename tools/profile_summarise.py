@@ -114,6 +114,12 @@ for prec in ("exact", "fast"):
         if "SQ_ACTIVE_INST_VALU" in vals and "GRBM_GUI_ACTIVE" in vals:
             # ACTIVE_INST_VALU counts quad-cycles summed over all SIMDs; GRBM_GUI_ACTIVE is summed over the XCDs
             d["valu_busy_fraction"] = vals["SQ_ACTIVE_INST_VALU"] * 4.0 / SIMDS / (vals["GRBM_GUI_ACTIVE"] / XCDS)
+        if "GRBM_GUI_ACTIVE" in vals and kernel:
+            # effective clock under this load (MI355X_MICROARCH.md, DVFS give-back): GRBM_GUI_ACTIVE is summed over the 8
+            # XCDs; the kernel's wall time from the --stats pass - a different run of the same command, so +-5 %
+            ns = next((float(r["AverageNs"]) for n_, r in stats.items() if n_.split("(")[0] == kernel), None)
+            if ns:
+                d["effective_clock_ghz"] = vals["GRBM_GUI_ACTIVE"] / XCDS / ns
         valu_out[prec] = {"kernel": kernel, **vals, "derived": d}
 if valu_out:
     path = os.path.join(root, "profiles", f"{tag}_{wl}_valu_pmc.json")
