@@ -193,8 +193,9 @@ def _population_chunk(acc, rewards, dones, half, worlds_per_member):
     alive = (live * (1 - 1 * dones[:executed])).sum(axis=0)                        # integers: any order
     acc["done_at"][...] += alive
     acc["total_steps"][...] += alive
-    means = np.stack([rewards[t].reshape(P, worlds_per_member, N, 1)[:, :, :half].mean(axis=(1, 2, 3))
-                      for t in range(executed)])                                   # the same call, step by step
+    # one member's mean of one step = the reference's `reward[:, :half].mean()` on that member's block of worlds
+    # (the same pairwise reduction per (step, member); tests G11 + tools/fuzz_fitness.py hold it to that)
+    means = rewards[:executed].reshape(executed, P, worlds_per_member, N, 1)[:, :, :, :half].mean(axis=(2, 3, 4))
     acc["sum_reward"][...] = np.add.accumulate(np.concatenate([acc["sum_reward"][None], run_t[:executed] * means]),
                                                axis=0)[-1]                         # added in step order
     running[...] = run_t[executed - 1] & ~all_done[executed - 1]

@@ -26,7 +26,11 @@ for chunk in chunks + chunks[:1]:
     res = get_fitness_population(env, pop, worlds_per_member=wpm, max_steps=max_steps, chunk=chunk)
     dt = time.perf_counter() - t0
     steps = env.step_count
+                                                             # a second generation on the same environment: no
+    t0 = time.perf_counter()                                 # device handle to (re)create, as in an ES loop
+    res2 = get_fitness_population(env, pop, worlds_per_member=wpm, max_steps=max_steps, chunk=chunk)
+    dt2 = time.perf_counter() - t0
     print(f"P={P} x {wpm} worlds of {dim}x{dim}, 4 agents, chunk={chunk}: {steps} steps in {dt:.3f} s = "
           f"{dt / steps * 1e6:.0f} us/step, {P * wpm * 4 * steps / dt / 1e6:.2f} M agent-steps/s, "
-          f"best fitness {max(r[0] for r in res):.4f}", flush=True)
+          f"best fitness {max(r[0] for r in res):.4f}; the next generation on the same env: {dt2:.3f} s", flush=True)
     env.close()
