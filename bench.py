@@ -30,7 +30,9 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with these extra
                timed region (dw_last_step_n_timing).  `traffic` = HBM bytes per launch from the PMC profile
                committed under profiles/ (collected separately, as the guide prescribes), `measured_frac` =
                traffic / launch time / peak; `valu` = VALU instructions per cell-evaluation and SIMD busy
-               fraction from the committed SQ counters; `bound` is what those counters say.
+               fraction from the committed SQ counters; `bound` is what those counters say.  `copy_ceiling` =
+               what a plain device copy reaches on this card, measured live (the practical ceiling
+               beside the spec peak), `measured_over_copy_ceiling` = the kernel's measured HBM rate / that.
   cpu_baseline the oracle's C restatement (oracle/daisy_oracle.c, "port") timed on this host's cores
                on a bounded sample of the same workload (rank 0, N=1 only).
 """
@@ -343,6 +345,28 @@ def main():
         eng.close()
         return res
 
+    def copy_ceiling(nbytes=1 << 30, reps=20):
+        """what a plain device copy reaches on THIS card (read nbytes + write nbytes per pass), the
+        practical ceiling beside the 8 TB/s spec: the better of hipMemcpyDtoD (Tensor.copy_) and an elementwise
+        kernel (torch.add, float32), timed with events on torch's stream after the engines are closed."""
+        a = torch.ones(nbytes // 4, dtype=torch.float32, device="cuda")
+        b = torch.empty_like(a)
+        best = {}
+        for name, op in (("memcpy_dtod", lambda: b.copy_(a)), ("elementwise_add", lambda: torch.add(a, 1.0, out=b))):
+            for _ in range(3):
+                op()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                op()
+            e1.record()
+            torch.cuda.synchronize()
+            best[name] = 2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del a, b
+        torch.cuda.empty_cache()
+        return {"GB/s": max(best.values()), "frac_of_peak": max(best.values()) / HBM_PEAK_GBS, "by_method": best,
+                "bytes_per_pass": 2 * nbytes}
+
     def roofline(m):
         """SURVEY 8(d) accounting for the dominant kernel of run `m` (see the module docstring)."""
         bpc = 4 * m["plane_elem_bytes"]                 # 2 planes read + 2 written, in the launch's storage format
@@ -414,6 +438,11 @@ def main():
     if not args.no_workloads and args.workload == "target":
         # BASELINE configs[1] in the same invocation: the whole luminosity ramp (512 steps after 64 of warm-up)
         out["workloads"] = {"c2": {p: brief(measure("c2", p, 512, 64, 0.5)) for p in ("exact", "fast")}}
+    if rank == 0:
+        cc = copy_ceiling()
+        out["roofline"]["copy_ceiling"] = cc
+        if out["roofline"]["traffic"]:
+            out["roofline"]["measured_over_copy_ceiling"] = out["roofline"]["measured_frac"] * HBM_PEAK_GBS / cc["GB/s"]
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(G)
         out["vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]

@@ -38,6 +38,7 @@ def test_bench_line_follows_the_contract():
     assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["launch_ms"] * 1e-3) / 1e9) / r["achieved"] < 1e-9
     assert 0.2 < r["frac"] <= 1.0 and r["peak"] == 8000.0 and r["unit"] == "GB/s" and r["bound"] in ("hbm", "valu")
     assert r["measured_frac"] is None or r["measured_frac"] <= r["frac"]
+    assert 2000.0 < r["copy_ceiling"]["GB/s"] <= 8000.0     # a device copy, live: below the spec peak, well above PCIe
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 1e6 and c["unit"] == "cell-updates/s" and c["sample"]
     for mode in d["modes"].values():
