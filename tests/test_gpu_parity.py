@@ -347,6 +347,58 @@ def test_multiworld_trajectory_vs_c_oracle(amd):
     eng.close()
 
 
+def test_distinct_handles_from_distinct_threads(amd):
+    """include/daisyworld_hip.h: a handle is not thread-safe, DISTINCT handles may be driven from distinct threads
+    (ctypes drops the GIL for the call): four threads, each with its own handle, kernel family and error slot, run a
+    trajectory concurrently; every one equals the oracle, and an error raised in one thread stays in that thread."""
+    import threading
+    from therldaisyworld_amd import _ffi
+    shapes = [(3, 256, 256, "exact"), (2, 64, 64, "exact"), (1, 40, 1024, "f64"), (5, 16, 16, "exact")]
+    steps, L, dL = 24, 0.75, 0.75 / 512                     # dyadic: L + t*dL is the oracle's repeated sum exactly
+    starts, results, errors = [], [None] * len(shapes), [None] * len(shapes)
+    for i, (B, H, W, prec) in enumerate(shapes):
+        light, dark = _random_quantised(np.random.RandomState(900 + i), B, H, W)
+        starts.append((light, dark))
+    gate = threading.Barrier(len(shapes))
+
+    def run(i):
+        try:
+            B, H, W, prec = shapes[i]
+            eng = _engine(amd, B, H, W, 0, prec)
+            eng.upload_state(*starts[i])
+            gate.wait(timeout=120)
+            for t in range(steps):                          # single steps and a fused run, interleaved with the others
+                if t == 8:
+                    eng.step_n(8, L + 8 * dL, dL, 0.75, 1.5)
+                elif t < 8 or t >= 16:
+                    eng.step(L + t * dL)
+            lib = _ffi.load()
+            if i == 0:                                      # an error lands in THIS thread's message slot only
+                assert lib.dw_upload_state_f64(eng._h, None, None) == _ffi.DW_EINVAL
+                assert b"null argument" in lib.dw_last_error()
+            gate.wait(timeout=120)
+            if i != 0:
+                assert b"null argument" not in (lib.dw_last_error() or b"")
+            results[i] = eng.download_planes()
+            eng.close()
+        except BaseException as e:                          # noqa: BLE001 - re-raised in the main thread
+            errors[i] = e
+            gate.abort()                                    # do not leave the others waiting
+
+    threads = [threading.Thread(target=run, args=(i,)) for i in range(len(shapes))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for e in errors:
+        if e is not None:
+            raise e
+    for i, (light, dark) in enumerate(starts):
+        l, d = light.copy(), dark.copy()
+        c_oracle.step_n(l, d, L, dL, steps)
+        assert np.array_equal(_k(results[i][0]), _k(l)) and np.array_equal(_k(results[i][1]), _k(d)), shapes[i]
+
+
 # ---------------------------------------------------------------------------------------------
 # the drop-in class against the reference fixtures
 # ---------------------------------------------------------------------------------------------

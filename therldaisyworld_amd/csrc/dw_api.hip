@@ -414,13 +414,11 @@ static int launch_tiled(dw_handle* h, const plane_t* iL, const plane_t* iD, plan
                         const PhysF32& P, const PhysF64& P64, StatsDev* stats,
                         unsigned long long* fixups, unsigned long long* zero_me, int zero_n, const FixQ& fq) {
     auto kern = step_tiled<TCQ, RPT, EXACT>;
-    static bool attr_set = false;   // per instantiation
-    if (!attr_set) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize,
+    // only the 32-row tuning tiles exceed the 64 KB a launch may ask for without opting in; the attribute belongs
+    // to the CURRENT device's copy of the kernel, so it is set per call (no process-wide flag: one handle per GPU)
+    if constexpr (TileCfg<TCQ, RPT>::LDS_BYTES > 64 * 1024)
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)(TileCfg<TCQ, RPT>::LDS_BYTES)));
-        attr_set = true;
-    }
     const unsigned grid = (unsigned)h->geom.chunk * 8u;
     constexpr size_t lds_bytes = TileCfg<TCQ, RPT>::LDS_BYTES;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, h->stream, iL, iD, oL, oD, h->geom, P, stats,
