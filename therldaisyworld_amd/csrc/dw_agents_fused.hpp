@@ -42,7 +42,7 @@ __device__ inline unsigned int fast1_word(const TI* __restrict__ pL, const TI* _
     const float Cd = (at(pD, ru, cl) + at(pD, ru, cr)) + (at(pD, rd, cl) + at(pD, rd, cr));
     const float li = at(pL, rr, cc), di = at(pD, rr, cc);
     const GrowthF32 g = growth_t<kFastSplit, float>(P, li, di, El, Cl, Ed, Cd);
-    return (unsigned int)finish_fast(li, g.gql) | ((unsigned int)finish_fast(di, g.gqd) << 16);
+    return (unsigned int)finish_fast(li, g.dKl, g.fl) | ((unsigned int)finish_fast(di, g.dKd, g.fd) << 16);
 }
 
 // the same map on nine already-evaluated (light | dark << 16) words of a 3x3 block, row-major
@@ -55,7 +55,7 @@ __device__ inline unsigned int fast_word_from9(const unsigned int* w, const Phys
     const float Ed = (d[3] + d[5]) + (d[1] + d[7]);
     const float Cd = (d[0] + d[2]) + (d[6] + d[8]);
     const GrowthF32 g = growth_t<kFastSplit, float>(P, l[4], d[4], El, Cl, Ed, Cd);
-    return (unsigned int)finish_fast(l[4], g.gql) | ((unsigned int)finish_fast(d[4], g.gqd) << 16);
+    return (unsigned int)finish_fast(l[4], g.dKl, g.fl) | ((unsigned int)finish_fast(d[4], g.dKd, g.fd) << 16);
 }
 
 struct LookaheadArgs {

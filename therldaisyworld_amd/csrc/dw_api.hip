@@ -265,7 +265,12 @@ static PhysF32 derive_f32(const dw_params& p, double L, int hb_cap = 40) {
     P.a1 = (float)((double)P.a1h + P.a1l); P.a2 = (float)((double)P.a2h + P.a2l);
     P.a3 = (float)((double)P.a3h + P.a3l); P.a4 = (float)((double)P.a4h + P.a4l);
     P.c0ls = (float)((double)P.c0lh + P.c0ll); P.c0ds = (float)((double)P.c0dh + c0dl);
-    P.cbeta = (float)(p.g * p.temp_optimal * p.temp_optimal);
+    // kbeta = 1 / sqrt(g * To^2) (dw_physics.hpp); g = 0 (beta = 1 everywhere): a denominator so large that w^2
+    // vanishes.  g < 0 is refused for the float32 modes by check_params.
+    {
+        const double cbeta = p.g * p.temp_optimal * p.temp_optimal;
+        P.kbeta = cbeta > 1e-30 ? (float)(1.0 / std::sqrt(cbeta)) : 0x1p60f;
+    }
     const PhysF64 P64 = make_f64(p, L);
     // dt folded into the density weights (dK = dt * density is what the map needs); the bare fraction then is
     // kb = p - (dKl + dKd) * 0.001 / dt  (dt = 0: no growth at all - weights 0, kb = p)
@@ -658,6 +663,8 @@ static int check_params(const dw_params* p) {
          "a world of %dx%d cells exceeds the 2^31-1 cells per world the kernels index", p->height, p->width);
     NEED(p->n_agents >= 0, DW_EINVAL, "n_agents < 0");
     NEED(p->precision >= 0 && p->precision <= 2, DW_EINVAL, "bad precision %d", p->precision);
+    NEED(p->precision == DW_PRECISION_F64 || p->g >= 0.0, DW_EINVAL,
+         "g < 0 (a growth curve opening upwards) is evaluated by DW_PRECISION_F64 only");
     NEED((double)p->batch * p->height * p->width < 9.0e18, DW_EINVAL, "too many cells");
     return DW_OK;
 }

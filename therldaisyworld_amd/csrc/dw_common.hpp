@@ -134,8 +134,8 @@ __device__ __forceinline__ void cells4(const PhysF32& P, const Row4& upL, const 
 #pragma unroll
             for (int e = 0; e < N; ++e) tie[i + e] = tl[e] || td[e];
         } else {
-            vl = finish_fast_t<T>(li, g.gql);
-            vd = finish_fast_t<T>(di, g.gqd);
+            vl = finish_fast_t<T>(li, g.dKl, g.fl);
+            vd = finish_fast_t<T>(di, g.dKd, g.fd);
         }
 #pragma unroll
         for (int e = 0; e < N; ++e) {

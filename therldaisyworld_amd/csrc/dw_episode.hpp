@@ -137,8 +137,8 @@ __device__ __forceinline__ void ep_forward(const PhysF32& P, const PhysF64& Q, c
                     ++nfix;
                 }
             } else {
-                kl = finish_fast(li, g.gql);
-                kd = finish_fast(di, g.gqd);
+                kl = finish_fast(li, g.dKl, g.fl);
+                kd = finish_fast(di, g.dKd, g.fd);
             }
             nxtL[c] = kl;
             nxtD[c] = kd;

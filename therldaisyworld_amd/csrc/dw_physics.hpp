@@ -148,7 +148,10 @@ __device__ inline NewCoverF64 cell_f64_lean(const PhysF64& P, const unsigned int
 //    ~2^-12 times smaller, so its roundings are negligible.  e_x then has one rounding (u*|e_x|).
 //  * the fourth root is taken on u = 1 + e as y = sqrt(sqrt(u)), but the deviation from the
 //    optimum temperature is formed as  (T_x - To)/To = y - 1 = e / ((y + 1)(y^2 + 1)),  which keeps
-//    the RELATIVE accuracy of e instead of cancelling two numbers near 1.
+//    the RELATIVE accuracy of e instead of cancelling two numbers near 1.  The growth curve only needs
+//    w = sqrt(g)*(T_x - To) = (y - 1)/kbeta (beta = 1 - w^2), so kbeta is folded into the denominator:
+//    t = fma(s, kbeta, kbeta) = kbeta*(s + 1), D = fma(y, t, t) = kbeta*(y + 1)(s + 1), w = e * rcp(D) -
+//    two packed instructions per species fewer than (y+1)*(s+1), e*rcp, cbeta*d, and two roundings fewer.
 // Constant PAIRS.  The hot kernels evaluate two cells per lane with packed float32 instructions, whose operands
 // are 64-bit: a wave-uniform constant splatted from ONE scalar register would occupy a whole SGPR pair (and an
 // instruction may read only one scalar pair, so a second constant had to be copied into VGPRs).  Constants are
@@ -174,7 +177,7 @@ struct PhysF32 {
     DW_PAIR(c0ls, c0ds, c0s);
     // dt * (daisy kernel weights): dK = dt * density comes straight out of the weighted sum
     DW_PAIR(dw0, dw1, dw01);
-    DW_PAIR(dw2, cbeta, dw2cb);  // cbeta = g * To^2:  beta = 1 - cbeta * ((T-To)/To)^2
+    DW_PAIR(dw2, kbeta, dw2kb);  // kbeta = 1 / sqrt(g * To^2):  beta = 1 - (((T-To)/To) / kbeta)^2
     DW_PAIR(p, ck, pck);         // bare fraction kb = p - (dKl + dKd) * ck,  ck = 0.001 / dt
     // exact-mode tie test (per-mille; om = 1 - beta = cbeta*((T-To)/To)^2 >= 0):
     //   |frac(gq)| > tie_lo - eA*|gq| - |dt*K|*(eK0 + eK1*om)   =>  re-evaluate in float64
@@ -248,6 +251,7 @@ template <> struct Lanes<dw_f32x2> {
 template <typename T>
 struct GrowthT {
     T gql, gqd;                  // per-mille growth dt*K*(kb*beta - gamma) for light, dark
+    T fl, fd;                    // the factor kb*beta - gamma alone (gq = dK * f)
     T dKl, dKd;                  // dt * density (per-mille), used by the tie bound
     T oml, omd;                  // 1 - beta_l, 1 - beta_d (>= 0), used by the tie bound
 };
@@ -291,26 +295,29 @@ __device__ __forceinline__ GrowthT<T> growth_t(const PhysF32& P, T li, T di, T E
         ed = base + V::hi(P.c0s);
     }
     // light
+    const T kbe = V::hi(P.dw2kb);
     const T sl = V::sqrt(one + el);
     const T yl = V::sqrt(sl);
-    const T dl = el * V::rcp((yl + one) * (sl + one));
-    const T cdl = V::hi(P.dw2cb) * dl;
-    const T bl = V::fma(-cdl, dl, one);                     // beta_l = 1 - cbeta*dl^2
+    const T tl = V::fma(sl, kbe, kbe);                      // kbeta*(s + 1)
+    const T wl = el * V::rcp(V::fma(yl, tl, tl));           // e / (kbeta*(y + 1)(s + 1)) = sqrt(cbeta)*(T_l - To)/To
+    const T bl = V::fma(-wl, wl, one);                      // beta_l = 1 - w^2
     // dark
     const T sd = V::sqrt(one + ed);
     const T yd = V::sqrt(sd);
-    const T dd = ed * V::rcp((yd + one) * (sd + one));
-    const T cdd = V::hi(P.dw2cb) * dd;
-    const T bd = V::fma(-cdd, dd, one);
+    const T td = V::fma(sd, kbe, kbe);
+    const T wd = ed * V::rcp(V::fma(yd, td, td));
+    const T bd = V::fma(-wd, wd, one);
     // dt * densities (per-mille) and the bare fraction (natural)
     GrowthT<T> o;
-    o.dKl = V::fma(V::lo(P.dw2cb), Cl, V::fma(V::hi(P.dw01), El, V::lo(P.dw01) * li));
-    o.dKd = V::fma(V::lo(P.dw2cb), Cd, V::fma(V::hi(P.dw01), Ed, V::lo(P.dw01) * di));
+    o.dKl = V::fma(V::lo(P.dw2kb), Cl, V::fma(V::hi(P.dw01), El, V::lo(P.dw01) * li));
+    o.dKd = V::fma(V::lo(P.dw2kb), Cd, V::fma(V::hi(P.dw01), Ed, V::lo(P.dw01) * di));
     const T kb = V::fma(-(o.dKl + o.dKd), V::hi(P.pck), V::lo(P.pck));
-    o.oml = cdl * dl;                                       // only the exact mode's tie bound reads these
-    o.omd = cdd * dd;
-    o.gql = o.dKl * V::fma(kb, bl, V::lo(P.gt));
-    o.gqd = o.dKd * V::fma(kb, bd, V::lo(P.gt));
+    o.oml = wl * wl;                                        // only the exact mode's tie bound reads these
+    o.omd = wd * wd;
+    o.fl = V::fma(kb, bl, V::lo(P.gt));
+    o.fd = V::fma(kb, bd, V::lo(P.gt));
+    o.gql = o.dKl * o.fl;                                   // the exact finaliser and the audit; the float32-only
+    o.gqd = o.dKd * o.fd;                                   // finaliser folds the product into k + gq (one rounding)
     return o;
 }
 
@@ -320,13 +327,14 @@ __device__ __forceinline__ GrowthF32 growth_f32(const PhysF32& P, float li, floa
     return growth_t<SPLIT, float>(P, li, di, El, Cl, Ed, Cd);
 }
 
-// FAST finaliser: k' = rint(clip(k + gq, 0, 1000)) — valid for any (also un-quantised) input.
+// FAST finaliser: k' = rint(clip(k + dK*f, 0, 1000)), the sum in one fused multiply-add (one rounding instead of
+// two, one instruction fewer) — valid for any (also un-quantised) input.
 template <typename T>
-__device__ __forceinline__ T finish_fast_t(T k, T gq) {
+__device__ __forceinline__ T finish_fast_t(T k, T dK, T f) {
 #pragma clang fp contract(off)
-    return Lanes<T>::rint(Lanes<T>::clip(k + gq));
+    return Lanes<T>::rint(Lanes<T>::clip(Lanes<T>::fma(dK, f, k)));
 }
-__device__ __forceinline__ float finish_fast(float k, float gq) { return finish_fast_t<float>(k, gq); }
+__device__ __forceinline__ float finish_fast(float k, float dK, float f) { return finish_fast_t<float>(k, dK, f); }
 
 // EXACT finaliser for an integer k: rint(k + gq) = k + rint(gq) unless gq is within the float32
 // error bound of a tie, in which case the cell's `tie` flag (one per lane of T) is raised and the caller

@@ -49,8 +49,8 @@ __global__ __launch_bounds__(256) void step_generic(const InT* __restrict__ inL,
 #undef DW_AT
             const GrowthF32 g = growth_f32<PREC != 1 || kFastSplit>(P, li, di, El, Cl, Ed, Cd);
             if (PREC == 1) {
-                kl = finish_fast(li, g.gql);
-                kd = finish_fast(di, g.gqd);
+                kl = finish_fast(li, g.dKl, g.fl);
+                kd = finish_fast(di, g.dKd, g.fd);
             } else {
                 bool tl, td;
                 kl = finish_exact(P, li, g.gql, g.dKl, g.oml, tl);
