@@ -108,7 +108,9 @@ typedef struct dw_params {
     int32_t reserved0;
     int64_t world_offset;     /* global id of world 0 of this shard; keys the device RNG so that an
                                  ensemble sharded over GPUs draws the same worlds as a single run */
-    double p, g, S, sigma, gamma, q, q2, dt;                         /* ref :32-52 */
+    double p, g, S, sigma, gamma, q, q2, dt;                         /* ref :32-52; g < 0 (a growth curve that opens
+                                                                        upwards) only with DW_PRECISION_F64: the float32
+                                                                        modes return DW_EINVAL for it */
     double albedo_bare, albedo_light, albedo_dark, temp_optimal;     /* ref :65-69 */
     double agent_gamma, food_chain_penalty;                          /* ref :55, :70 */
     double initial_al, initial_ad, light_proportion, dark_proportion;/* ref :73-77 */

@@ -231,6 +231,9 @@ def test_exact_mode_uses_float32_path_and_few_fixups(amd):
     dict(dt=0.5),
     dict(dt=2.0, albedo_light=0.8, albedo_dark=0.2),
     dict(gamma=0.3, temp_optimal=290.0, g=0.004),
+    dict(g=0.0),                                      # flat growth curve: beta = 1 (kappa = 1/(sqrt(g)*To) unbounded)
+    dict(g=1e-9),
+    dict(g=0.05, temp_optimal=310.0),                 # narrow curve: beta << 0 almost everywhere
 ])
 def test_exact_mode_other_constants(amd, over):
     rng = np.random.RandomState(11)
@@ -244,6 +247,26 @@ def test_exact_mode_other_constants(amd, over):
         gl, gd = eng.download_planes()
         assert np.array_equal(_k(gl), _k(ref[:, 1])) and np.array_equal(_k(gd), _k(ref[:, 2]))
         eng.close()
+
+
+def test_negative_growth_curvature_is_float64_only(amd):
+    """g < 0 (a parabola opening upwards) breaks the float32 map's sqrt(g) and the tie bound's om >= 0: the float32
+    modes refuse it loudly, DW_PRECISION_F64 evaluates it like the reference's formulas."""
+    from therldaisyworld_amd import _ffi
+    rng = np.random.RandomState(12)
+    B, H, W = 2, 32, 64
+    light, dark = _random_quantised(rng, B, H, W)
+    for prec in ("exact", "fast"):
+        with pytest.raises(amd.DaisyHipError) as e:
+            _engine(amd, B, H, W, 0, prec, g=-0.001)
+        assert e.value.code == _ffi.DW_EINVAL and "g < 0" in str(e.value)
+    eng = _engine(amd, B, H, W, 0, "f64", g=-0.001)
+    eng.upload_state(light, dark)
+    eng.step(1.1)
+    gl, gd = eng.download_planes()
+    ref = c_oracle.forward(light, dark, 1.1, _oracle_params(g=-0.001))
+    assert np.array_equal(_k(gl), _k(ref[:, 1])) and np.array_equal(_k(gd), _k(ref[:, 2]))
+    eng.close()
 
 
 # ---------------------------------------------------------------------------------------------
