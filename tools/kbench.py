@@ -45,5 +45,5 @@ env = {k[3:]: v for k, v in os.environ.items() if k.startswith("DW_") and k != "
 for label, eng, L, times in arms:
     med, mn = statistics.median(times), min(times)
     print(f"{label:22s} B={a.B} G={a.G} ms/step med={med:.4f} min={mn:.4f} max={max(times):.4f} "
-          f"GB/s(med)={16 * cells / med / 1e6:.0f} frac={16 * cells / med / 1e6 / 8000:.3f} "
+          f"GB/s(med)={8 * cells / med / 1e6:.0f} frac={8 * cells / med / 1e6 / 8000:.3f} "   # binary16 planes: 8 B per cell-update
           f"fixups={eng.last_fixup_count()} env={env} :: {eng.kernel_info()[:44]}")
