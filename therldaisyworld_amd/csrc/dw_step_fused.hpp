@@ -188,6 +188,13 @@ __device__ __forceinline__ void fused2_body(const TI* __restrict__ inL, const TI
         w.d = stream_load4_raw(pD + (size_t)rr * G.W + col);
         return w;
     };
+    // The edge sums of a prefetched row are wanted HERE: left alone, the compiler sinks the adds (and half of the
+    // conversions) past the next iteration's store branch while the cross-lane moves, being convergent, stay, so the
+    // v_mov_b32_dpp + v_add_f32 pairs end up in different basic blocks and cannot fold into v_add_f32_dpp
+    // (4 instructions per row).  No instruction is emitted for the pin itself.
+    auto pin_edge_sums = [&](Row4& L, Row4& D) {
+        asm volatile("" : "+v"(L.h2[0]), "+v"(L.h2[3]), "+v"(D.h2[0]), "+v"(D.h2[3]));
+    };
     auto nbrs = [&](const float4& v, float& a, float& c) {
         if (PACK) { a = __shfl(v.w, lsrc, 64); c = __shfl(v.x, rsrc, 64); }
         else if (ROT) { a = dpp_mov_nb<kDppWaveRor1>(v.w); c = dpp_mov_nb<kDppWaveRol1>(v.x); }
@@ -345,6 +352,7 @@ __device__ __forceinline__ void fused2_body(const TI* __restrict__ inL, const TI
                     to_rows4(make_float4(l1[0], l1[1], l1[2], l1[3]), make_float4(d1[0], d1[1], d1[2], d1[3]), SL[u], SD[u]);
                     __builtin_amdgcn_sched_barrier(0);
                     to_rows4(widen4(nx.l), widen4(nx.d), IL[(u + 2) % 3], ID[(u + 2) % 3]);   // input row j+2 replaces input row j-1
+                    if (!PACK) pin_edge_sums(IL[(u + 2) % 3], ID[(u + 2) % 3]);
                 }
             }
         };
