@@ -81,3 +81,20 @@ def test_step_kernels_register_budgets_and_clean_hot_loops(asm):
                 assert info["NumVgprs"] <= 168 and info["Occupancy"] >= 3, (name, info["NumVgprs"])
             else:
                 assert info["NumVgprs"] <= 256 and info["Occupancy"] >= 2, (name, info["NumVgprs"])
+
+
+def test_fused_float32_kernels_instruction_budget(asm):
+    """The float32 step-pair kernels are VALU-issue-bound: their speed IS their instruction count.
+    One iteration of the hot loop = 3 rows x 4 columns x 2 steps = 24 cell-evaluations per lane; budget: 33 VALU
+    instructions per cell-evaluation for the plain variants (round 2 ends at 32.4-33.0: 18 packed + 6 transcendental
+    + 4 clamp/round + 1.5 conversions + neighbour sums), with every edge-column sum folded into v_add_f32_dpp where
+    the neighbour needs no `old` value."""
+    ks = _kernels(asm)
+    for mode in (0, 1):                                    # overlapped strips, in-wave rotation (W = 256)
+        name = next(n for n in ks if f"step_stream_fused2ILi{mode}ELb0ELb0E" in n)
+        loop = _hot_loop(ks[name][1])
+        valu = [ln for ln in loop if ln.startswith("\tv_")]
+        trans = [ln for ln in valu if re.match(r"\tv_(sqrt|rcp)_f32", ln)]
+        assert len(trans) == 144, (name, len(trans))        # 24 cell-evaluations x 6
+        assert len(valu) <= 33 * 24, (name, len(valu))
+        assert not any(ln.startswith("\tv_mov_b32_dpp") for ln in loop), name
