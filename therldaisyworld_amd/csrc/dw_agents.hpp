@@ -17,7 +17,8 @@ __global__ void agents_update(T* __restrict__ L, T* __restrict__ D,
                               int* __restrict__ idx, double* __restrict__ st,
                               const int* __restrict__ action, int act_b, int act_n, int B, int N,
                               int H, int W, double agent_gamma, int do_clip,
-                              double* __restrict__ reward = nullptr, unsigned char* __restrict__ done = nullptr) {
+                              double* __restrict__ reward = nullptr, unsigned char* __restrict__ done = nullptr,
+                              unsigned char* __restrict__ agent_ok = nullptr) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     const size_t woff = (size_t)b * H * W;
@@ -57,6 +58,11 @@ __global__ void agents_update(T* __restrict__ L, T* __restrict__ D,
             const double r = s * (s > 0.0 ? 1.0 : 0.0);
             reward[(size_t)b * N + n] = r;
             done[(size_t)b * N + n] = r < 0.1 ? 1 : 0;
+        }
+    if (agent_ok)    // the episode harness's per-step flag (= !done) of a step pair's first step
+        for (int n = 0; n < N; ++n) {
+            const double s = st[(size_t)b * N + n];
+            agent_ok[(size_t)b * N + n] = (s * (s > 0.0 ? 1.0 : 0.0)) < 0.1 ? 0 : 1;
         }
 }
 
@@ -251,12 +257,6 @@ __global__ void episode_flags(const StatsDev* __restrict__ stats, const double* 
         const double rw = s * (s > 0.0 ? 1.0 : 0.0);
         agent_ok[i] = rw < 0.1 ? 0 : 1;
     }
-}
-__global__ void agent_flags(const double* __restrict__ st, int n, unsigned char* __restrict__ agent_ok) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const double s = st[i];
-    agent_ok[i] = (s * (s > 0.0 ? 1.0 : 0.0)) < 0.1 ? 0 : 1;
 }
 __global__ void actions_from_table(const signed char* __restrict__ table, int n, int* __restrict__ action) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

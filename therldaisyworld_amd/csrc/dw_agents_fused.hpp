@@ -67,7 +67,7 @@ struct LookaheadArgs {
     // per-step "biosphere alive" flags (max cover > thr/1000) of the two steps, or null; pstats[2b], [2b+1]:
     // the fused launch's exact step-1 maximum and its count of certain step-2 row groups above thr
     unsigned char* alive_t; unsigned char* alive_t1;
-    const unsigned int* pstats; unsigned int thr;
+    unsigned int* pstats; unsigned int thr;      // (the patch kernel clears its world's two words after reading them)
     int B, N, H, W, mask;
     double agent_gamma;
     PhysF32 P1, P2;                              // float32 coefficient sets of steps t, t+1 (fast mode)
@@ -79,7 +79,10 @@ __global__ __launch_bounds__(64) void agents_lookahead_patch(LookaheadArgs A) {
     using TI = plane_t;
     using TO = plane_t;
     __shared__ unsigned int s_s1[kLookaheadMaxAgents][5];      // S1 at centre, (r,c-1), (r-1,c), (r+1,c), (r,c+1)
+    __shared__ unsigned int s_w[kLookaheadMaxAgents][25];      // S1' on the 5x5 block around a grazed cell, row-major
     __shared__ int s_act[kLookaheadMaxAgents];
+    __shared__ int s_ar[kLookaheadMaxAgents], s_ac[kLookaheadMaxAgents];   // the world's agents: loaded once, written back once
+    __shared__ double s_st[kLookaheadMaxAgents];
     __shared__ int s_gr[kLookaheadMaxAgents], s_gc[kLookaheadMaxAgents];
     __shared__ int s_ng;
     const int b = blockIdx.x, lane = threadIdx.x;
@@ -96,14 +99,25 @@ __global__ __launch_bounds__(64) void agents_lookahead_patch(LookaheadArgs A) {
         return EXACT ? exact1_word(pL, pD, H, W, r, c, Pa) : fast1_word(pL, pD, H, W, r, c, A.P1);
     };
 
-    // ---- A: what each agent sees after forward_t, and its action for step t+1 ----
+    // ---- A: what each agent sees after forward_t (one (agent, cell) evaluation per lane), and its action for
+    //         step t+1 ----
     if (lane < N) {
         const int an = b * N + lane;
-        const int ar = A.idx[(size_t)an * 2], ac = A.idx[(size_t)an * 2 + 1];
+        s_ar[lane] = A.idx[(size_t)an * 2];
+        s_ac[lane] = A.idx[(size_t)an * 2 + 1];
+        s_st[lane] = A.st[an];
+    }
+    __syncthreads();
+    {
         const int dr[5] = {0, 0, -1, 1, 0}, dc[5] = {0, -1, 0, 0, 1};      // centre, then Greedy's order 3,1,7,5
-        unsigned int v[5];
-#pragma unroll
-        for (int i = 0; i < 5; ++i) { v[i] = step1(ar + dr[i], ac + dc[i]); s_s1[lane][i] = v[i]; }
+        for (int t = lane; t < N * 5; t += 64) {
+            const int n = t / 5, i = t - n * 5;
+            s_s1[n][i] = step1(s_ar[n] + dr[i], s_ac[n] + dc[i]);
+        }
+    }
+    __syncthreads();
+    if (lane < N) {
+        const int an = b * N + lane;
         int a = (int)A.code[an];
         if (a < 0) {                                                       // ref Greedy.__call__ :18-30
             const bool argmin = a == -2;
@@ -112,9 +126,10 @@ __global__ __launch_bounds__(64) void agents_lookahead_patch(LookaheadArgs A) {
             double bestv = 0.0;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
+                const unsigned int w = s_s1[lane][i + 1];
                 double val = 0.0;
                 if ((A.mask >> cand[i]) & 1)
-                    val = (double)(float)(v[i + 1] & 0xffffu) / 1000.0 + (double)(float)(v[i + 1] >> 16) / 1000.0;
+                    val = (double)(float)(w & 0xffffu) / 1000.0 + (double)(float)(w >> 16) / 1000.0;
                 if (i == 0 || (argmin ? val < bestv : val > bestv)) { best = i; bestv = val; }
             }
             a = 4 + best;
@@ -124,15 +139,15 @@ __global__ __launch_bounds__(64) void agents_lookahead_patch(LookaheadArgs A) {
     if (lane == 0) s_ng = 0;
     __syncthreads();
 
-    // ---- B: update_agents of step t+1 (ref :181-244), agents in order ----
+    // ---- B: update_agents of step t+1 (ref :181-244), agents in order (one lane, on the LDS copies) ----
     if (lane == 0) {
-        for (int n = 0; n < N; ++n) A.st[(size_t)b * N + n] -= A.agent_gamma;                  // ref :184
+        for (int n = 0; n < N; ++n) s_st[n] -= A.agent_gamma;                                  // ref :184
         int ng = 0;
         for (int n = 0; n < N; ++n) {
-            double s = A.st[(size_t)b * N + n];
+            double s = s_st[n];
             if (s > 0.0) {                                                                  // ref :189
                 const int a = s_act[n];
-                int r = A.idx[((size_t)b * N + n) * 2], c = A.idx[((size_t)b * N + n) * 2 + 1];
+                int r = s_ar[n], c = s_ac[n];
                 int which = 0;                                                              // slot of s_s1 it lands on
                 if (a != 8) {                                                               // ref :191-206
                     const int m = ((a % 4) + 4) % 4;
@@ -141,8 +156,8 @@ __global__ __launch_bounds__(64) void agents_lookahead_patch(LookaheadArgs A) {
                 }
                 r = ((r % H) + H) % H;                                                      // ref :208
                 c = ((c % W) + W) % W;
-                A.idx[((size_t)b * N + n) * 2] = r;
-                A.idx[((size_t)b * N + n) * 2 + 1] = c;
+                s_ar[n] = r;
+                s_ac[n] = c;
                 if (a > 4) {                                                                // ref :210-216
                     bool eaten = false;                       // an earlier agent of this step emptied the cell
                     for (int g = 0; g < ng; ++g) eaten = eaten || (s_gr[g] == r && s_gc[g] == c);
@@ -151,35 +166,45 @@ __global__ __launch_bounds__(64) void agents_lookahead_patch(LookaheadArgs A) {
                         s += (double)(float)(w & 0xffffu) / 1000.0 + (double)(float)(w >> 16) / 1000.0;
                         s_gr[ng] = r; s_gc[ng] = c; ++ng;
                     }
-                    A.st[(size_t)b * N + n] = s;
+                    s_st[n] = s;
                 }
             }
-        }
-        for (int n = 0; n < N; ++n) {                                                        // ref :244
-            const double s = A.st[(size_t)b * N + n];
-            const double cl = s < 0.0 ? 0.0 : (s > 1.0 ? 1.0 : s);
-            A.st[(size_t)b * N + n] = cl;
-            if (A.agent_ok) A.agent_ok[(size_t)b * N + n] = (cl * (cl > 0.0 ? 1.0 : 0.0)) < 0.1 ? 0 : 1;
         }
         s_ng = ng;
     }
     __syncthreads();
+    if (lane < N) {                                                                          // ref :244, and the write-back
+        const int an = b * N + lane;
+        const double s = s_st[lane];
+        const double cl = s < 0.0 ? 0.0 : (s > 1.0 ? 1.0 : s);
+        A.st[an] = cl;
+        A.idx[(size_t)an * 2] = s_ar[lane];
+        A.idx[(size_t)an * 2 + 1] = s_ac[lane];
+        if (A.agent_ok) A.agent_ok[an] = (cl * (cl > 0.0 ? 1.0 : 0.0)) < 0.1 ? 0 : 1;
+    }
 
     // ---- C: S2 on the 3x3 blocks around the grazed cells, from S1' ----
+    // two parallel stages: the 5x5 block of S1' values around every grazed cell (one evaluation per lane and pass,
+    // each from S0' in memory), then the 9 S2 values of its inner 3x3 block from those (LDS) - instead of nine
+    // S1 evaluations one after the other in every S2 lane (the kernel is pure latency: one wave per world)
     const int ng = s_ng;
+    for (int p = lane; p < ng * 25; p += 64) {
+        const int g = p / 25, t = p - g * 25;
+        const int yr = ((s_gr[g] + t / 5 - 2) % H + H) % H, yc = ((s_gc[g] + t % 5 - 2) % W + W) % W;
+        bool grazed = false;
+        for (int k = 0; k < ng; ++k) grazed = grazed || (s_gr[k] == yr && s_gc[k] == yc);
+        s_w[g][t] = grazed ? 0u : step1(yr, yc);
+    }
+    __syncthreads();
     for (int p = lane; p < ng * 9; p += 64) {
         const int g = p / 9, t = p - g * 9;
-        const int xr = ((s_gr[g] + t / 3 - 1) % H + H) % H, xc = ((s_gc[g] + t % 3 - 1) % W + W) % W;
+        const int tr = t / 3, tc = t - tr * 3;                   // the S2 cell is block cell (tr + 1, tc + 1) of the 5x5
+        const int xr = ((s_gr[g] + tr - 1) % H + H) % H, xc = ((s_gc[g] + tc - 1) % W + W) % W;
         unsigned int w2[9];
 #pragma unroll
         for (int a = 0; a < 3; ++a)
 #pragma unroll
-            for (int e = 0; e < 3; ++e) {
-                const int yr = ((xr + a - 1) % H + H) % H, yc = ((xc + e - 1) % W + W) % W;
-                bool grazed = false;
-                for (int k = 0; k < ng; ++k) grazed = grazed || (s_gr[k] == yr && s_gc[k] == yc);
-                w2[a * 3 + e] = grazed ? 0u : step1(yr, yc);
-            }
+            for (int e = 0; e < 3; ++e) w2[a * 3 + e] = s_w[g][(tr + a) * 5 + (tc + e)];
         unsigned int out;
         if (EXACT) {
             const NewCoverF64 o = cell_f64_lean(Pb, w2);
@@ -194,11 +219,14 @@ __global__ __launch_bounds__(64) void agents_lookahead_patch(LookaheadArgs A) {
 
     // ---- D: the two steps' "biosphere alive" flags ----
     if (A.alive_t) {
-        if (lane == 0) A.alive_t[b] = A.pstats[2 * b] > A.thr ? 1 : 0;                       // max of S1
+        const unsigned int max1 = A.pstats[2 * b], sure2 = A.pstats[2 * b + 1];
+        __syncthreads();                                          // every lane has read them:
+        if (lane == 0) { A.pstats[2 * b] = 0u; A.pstats[2 * b + 1] = 0u; }   // cleared for the next pair's fused launch
+        if (lane == 0) A.alive_t[b] = max1 > A.thr ? 1 : 0;                                  // max of S1
         // step t+1: the fused launch counted row groups that certainly hold a value > thr; the patches
         // above touched at most 9 * ng cells, i.e. at most 9 * ng groups.  More groups than that: alive,
         // without looking.  Otherwise (a dying world) look at every cell of the patched result.
-        if (A.pstats[2 * b + 1] > 9u * (unsigned int)ng) {
+        if (sure2 > 9u * (unsigned int)ng) {
             if (lane == 0) A.alive_t1[b] = 1;
         } else {
             __threadfence_block();

@@ -589,7 +589,7 @@ static int launch_forward_fused2(dw_handle* h, double L1, double L2, unsigned in
 }
 
 static int launch_agents(dw_handle* h, const int* d_action, int act_b, int act_n, bool standalone = false,
-                         double* d_reward = nullptr, unsigned char* d_done = nullptr) {
+                         double* d_reward = nullptr, unsigned char* d_done = nullptr, unsigned char* d_ok = nullptr) {
     const dw_params& p = h->prm;
     if (p.n_agents == 0) return DW_OK;
     NEED(h->have_state, DW_ESTATE, "no state uploaded");
@@ -601,7 +601,7 @@ static int launch_agents(dw_handle* h, const int* d_action, int act_b, int act_n
 #define DW_AG(T, PL, PD)                                                                                          \
     hipLaunchKernelGGL(agents_update<T>, dim3(blocks), dim3(64), 0, h->stream, PL, PD, h->idx, h->st, d_action,    \
                        act_b, act_n, p.batch, p.n_agents, p.height, p.width, p.agent_gamma,                        \
-                       p.collision_mode == 0 ? 1 : 0, d_reward, d_done)
+                       p.collision_mode == 0 ? 1 : 0, d_reward, d_done, d_ok)
     if (h->unq == OWN_CUR) {                       // grazing on the un-quantised state, in its own format
         if (h->unq_kind == UNQ_F64) DW_AG(double, h->L64, h->D64); else DW_AG(float, h->U32L, h->U32D);
     } else {
@@ -1658,6 +1658,12 @@ static int run_episode_stepwise(dw_handle* h, int32_t nsteps, const double* L_sc
     // With per-step world flags the fused launch also reduces what the flags of both steps need (STATS
     // variants: exact step-1 maximum, count of certain step-2 values above the threshold).
     unsigned int* pstats = world_alive ? reinterpret_cast<unsigned int*>(h->ep_buf + o_ps) : nullptr;
+    // zeroed once: every agents_lookahead_patch launch leaves its world's words cleared for the next pair
+    if (pstats && may_pair) HIPCHK(hipMemsetAsync(pstats, 0, sizeof(unsigned int) * 2 * B, h->stream));
+    // action codes of a pair's second step when they come from no table: one byte value for the whole episode
+    const int uniform_code = policy_mode == DW_POLICY_ZEROS ? 0 : (policy_mode == DW_POLICY_ARGMIN ? 0xFE : 0xFF);
+    if (may_pair && policy_mode != DW_POLICY_TABLE)
+        HIPCHK(hipMemsetAsync(h->ep_buf + o_code, uniform_code, bn, h->stream));
     auto greedy = [&](int argmin, int codes) { return launch_policy_greedy(h, argmin, nullptr, codes); };
     for (size_t t = 0; t < K; ++t) {
         const bool pair = may_pair && cur_quantised(h) && K - t >= 3;
@@ -1673,25 +1679,17 @@ static int run_episode_stepwise(dw_handle* h, int32_t nsteps, const double* L_sc
                 if (int prc = greedy(policy_mode == DW_POLICY_ARGMIN ? 1 : 0, 0)) return prc;
             }
             HIPCHK(hipGetLastError());
-            int rc = launch_agents(h, h->action, B, N);
+            // a pair's first step: the agents' ok flags straight from the grazing kernel
+            int rc = launch_agents(h, h->action, B, N, false, nullptr, nullptr, pair ? h->ep_buf + o_ok + t * bn : nullptr);
             if (rc) return rc;
         }
         if (pair) {
-            hipLaunchKernelGGL(agent_flags, dim3((unsigned)((bn + 255) / 256)), dim3(256), 0, h->stream, h->st, (int)bn,
-                               h->ep_buf + o_ok + t * bn);
             const double L1 = L_schedule[t], L2 = L_schedule[t + 1];
-            if (pstats) HIPCHK(hipMemsetAsync(pstats, 0, sizeof(unsigned int) * 2 * B, h->stream));
-            int rc = launch_forward_fused2(h, L1, L2, pstats, (float)threshold_k);
+            int rc = launch_forward_fused2(h, L1, L2, pstats, (float)threshold_k);   // pstats: zero (see above)
             if (rc) return rc;
             // codes of step t+1: the caller's table slice, or one byte value for the whole ensemble
             const bool tab2 = policy_mode == DW_POLICY_TABLE || (use_table && use_table[t + 1]);
-            unsigned char* codes = h->ep_buf + o_code;
-            if (tab2) {
-                codes = h->ep_buf + o_tab + (t + 1) * bn;
-            } else {
-                const int v = policy_mode == DW_POLICY_ZEROS ? 0 : (policy_mode == DW_POLICY_ARGMIN ? 0xFE : 0xFF);
-                HIPCHK(hipMemsetAsync(codes, v, bn, h->stream));
-            }
+            unsigned char* codes = tab2 ? h->ep_buf + o_tab + (t + 1) * bn : h->ep_buf + o_code;
             LookaheadArgs A;
             A.inL = h->L16[1 - h->cur]; A.inD = h->D16[1 - h->cur];
             A.outL = h->L16[h->cur]; A.outD = h->D16[h->cur];
