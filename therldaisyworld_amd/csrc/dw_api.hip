@@ -457,7 +457,8 @@ static int launch_forward(dw_handle* h, double L) {
     fq.counts = reinterpret_cast<unsigned int*>(stats + p.batch + 1);
     fq.qcap = h->qcap;
     fq.redo_tiles = h->redo_tiles;
-    const dim3 ggrid((unsigned)((p.height * p.width + 255) / 256), (unsigned)p.batch);
+    const int gcpt = generic_cells_per_thread(p.batch, (long long)p.height * p.width);
+    const dim3 ggrid((unsigned)(((long long)p.height * p.width + 256LL * gcpt - 1) / (256LL * gcpt)), (unsigned)p.batch);
     int prec = p.precision;
 #ifdef DW_TUNING
     if (const char* e = std::getenv("DW_ABLATE")) {
@@ -479,7 +480,7 @@ static int launch_forward(dw_handle* h, double L) {
         // float64 (exact and f64 modes: bit-identical to the reference's first step) or float32 (fast mode)
 #define DW_GEN(T, PR, IL, ID)                                                                                     \
     hipLaunchKernelGGL((step_generic<T, PR>), ggrid, dim3(256), 0, h->stream, IL, ID, h->L16[out], h->D16[out],   \
-                       p.height, p.width, P, P64, stats, fixups, zero_me, zero_n)
+                       p.height, p.width, P, P64, stats, fixups, zero_me, zero_n, gcpt)
         const bool f32arith = prec == DW_PRECISION_FAST;
         if (h->unq_kind == UNQ_F64) { if (f32arith) DW_GEN(double, 1, h->L64, h->D64); else DW_GEN(double, 2, h->L64, h->D64); }
         else { if (f32arith) DW_GEN(float, 1, h->U32L, h->U32D); else DW_GEN(float, 2, h->U32L, h->U32D); }

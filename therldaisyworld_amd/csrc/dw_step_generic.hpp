@@ -7,8 +7,19 @@
 namespace dw {
 
 // ---------------------------------------------------------------------------------------------
-// step_generic: grid = (ceil(H*W/256), B), block = 256.  PREC: 0 exact, 1 fast, 2 f64.
+// step_generic: grid = (ceil(H*W/(256*cpt)), B), block = 256; a thread evaluates `cpt` cells (256 apart) and the
+// wave issues ONE set of reduction atomics for all of them: with one set per 64 cells the first step of the
+// north-star shape (2.7e8 waves x 3 atomics on 1024 x 3 addresses) took 0.65 s in either arithmetic.
+// generic_cells_per_thread() picks cpt so that the launch still has a few thousand workgroups.
+// PREC: 0 exact, 1 fast, 2 f64.
 // ---------------------------------------------------------------------------------------------
+__host__ inline int generic_cells_per_thread(long long batch, long long cells_per_world) {
+    long long cpt = batch * cells_per_world / (256LL * 8192);          // big jobs: still >= 8192 workgroups
+    const long long few = cells_per_world / (256LL * 512);              // any job: <= 512 atomic sets per world
+    cpt = cpt > few ? cpt : few;
+    return (int)(cpt < 1 ? 1 : (cpt > 32 ? 32 : cpt));                   // <= 32: float partial sums stay exact
+}
+
 template <typename InT, int PREC>
 __global__ __launch_bounds__(256) void step_generic(const InT* __restrict__ inL,
                                                     const InT* __restrict__ inD,
@@ -18,15 +29,19 @@ __global__ __launch_bounds__(256) void step_generic(const InT* __restrict__ inL,
                                                     StatsDev* __restrict__ stats,
                                                     unsigned long long* __restrict__ fixups,
                                                     unsigned long long* __restrict__ zero_me,
-                                                    int zero_n) {
+                                                    int zero_n, int cpt = 1) {
     const int b = blockIdx.y;
-    const int cell = blockIdx.x * 256 + threadIdx.x;
     const size_t woff = (size_t)b * H * W;
-    float kl = 0.f, kd = 0.f;
-    bool fixed = false;
+    float mx = 0.f, suml = 0.f, sumd = 0.f;       // integers <= 1000 * cpt: exact in float32
+    unsigned int nfixed = 0;
     if (blockIdx.x == 0 && blockIdx.y == 0)      // clear the reduction buffer of the NEXT step
         for (int i = threadIdx.x; i < zero_n; i += 256) zero_me[i] = 0ull;
-    if (cell < H * W) {
+    for (int it = 0; it < cpt; ++it) {
+    const unsigned int ucell = (blockIdx.x * (unsigned int)cpt + it) * 256u + threadIdx.x;   // H*W < 2^31: no wrap
+    const int cell = (int)ucell;
+    float kl = 0.f, kd = 0.f;
+    bool fixed = false;
+    if (ucell < (unsigned int)(H * W)) {
         const int r = cell / W, c = cell - r * W;
         const InT* pl = inL + woff;
         const InT* pd = inD + woff;
@@ -69,14 +84,28 @@ __global__ __launch_bounds__(256) void step_generic(const InT* __restrict__ inL,
         outL[woff + cell] = (plane_t)kl;
         outD[woff + cell] = (plane_t)kd;
     }
-    // per-world reductions: wave shuffles, then one set of atomics per wave
-    const float m = wave_max(fmaxf(kl, kd));
-    const float sl = wave_sum(kl), sd = wave_sum(kd);
-    const unsigned long long nf = __popcll(__ballot(fixed));
-    if ((threadIdx.x & 63) == 0) {
-        atomicMax(&stats[b].max_k, (unsigned int)m);
-        atomicAdd(&stats[b].sum_l, (unsigned long long)sl);
-        atomicAdd(&stats[b].sum_d, (unsigned long long)sd);
+    mx = fmaxf(mx, fmaxf(kl, kd));
+    suml += kl;
+    sumd += kd;
+    nfixed += fixed ? 1u : 0u;
+    }
+    // per-world reductions: wave shuffles, the four waves through LDS, then one set of atomics per workgroup
+    // (same-address atomics cost ~100 ns each: they, not the arithmetic, bound this kernel on few-world jobs)
+    __shared__ float s_red[4][4];
+    const int wv = threadIdx.x >> 6;
+    const float m = wave_max(mx);
+    const float sl = wave_sum(suml), sd = wave_sum(sumd);
+    const float nfw = wave_sum((float)nfixed);
+    if ((threadIdx.x & 63) == 0) { s_red[wv][0] = m; s_red[wv][1] = sl; s_red[wv][2] = sd; s_red[wv][3] = nfw; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float bm = fmaxf(fmaxf(s_red[0][0], s_red[1][0]), fmaxf(s_red[2][0], s_red[3][0]));
+        const float bl = (s_red[0][1] + s_red[1][1]) + (s_red[2][1] + s_red[3][1]);      // <= 256 * 32 * 1000: exact
+        const float bd = (s_red[0][2] + s_red[1][2]) + (s_red[2][2] + s_red[3][2]);
+        const unsigned long long nf = (unsigned long long)((s_red[0][3] + s_red[1][3]) + (s_red[2][3] + s_red[3][3]));
+        atomicMax(&stats[b].max_k, (unsigned int)bm);
+        atomicAdd(&stats[b].sum_l, (unsigned long long)bl);
+        atomicAdd(&stats[b].sum_d, (unsigned long long)bd);
         if (nf) atomicAdd(fixups, nf);
     }
 }
