@@ -77,7 +77,8 @@ def test_step_kernels_register_budgets_and_clean_hot_loops(asm):
             assert info["Occupancy"] >= (3 if three else 4), (name, info["NumVgprs"])
         else:
             plain_fused = any(f"fused2_exactILi{m}ELb0ELb0E" in name for m in (0, 1, 2))   # not packed, no STATS
-            if "step_stream_exactILi" in name or plain_fused:
+            stats_fused = any(f"fused2_exactILi{m}ELb0ELb1E" in name for m in (0, 1))      # STATS, not the ring
+            if "step_stream_exactILi" in name or plain_fused or stats_fused:
                 assert info["NumVgprs"] <= 168 and info["Occupancy"] >= 3, (name, info["NumVgprs"])
             else:
                 assert info["NumVgprs"] <= 256 and info["Occupancy"] >= 2, (name, info["NumVgprs"])

@@ -641,11 +641,12 @@ void step_stream_fused2(const plane_t* __restrict__ inL, const plane_t* __restri
     fused2_body<MODE, false, PACK, STATS>(inL, inD, outL, outD, G, P1, P2, dummy, zero, zero, zero_me, zero_n, pstats, thr_hi);
 }
 
-// Waves per SIMD of the exact kernels: the plain variants fit 3 waves/SIMD (153-155 VGPRs); the packed and
-// STATS variants would spill 44-80 B per lane there (measured 30 % slower) and stay at 2.
-template <bool PACK, bool STATS>
+// Waves per SIMD of the exact kernels: the plain variants fit 3 waves/SIMD (151-161 VGPRs), and since the constant
+// pairs so do the STATS variants of the overlapped and rotating strips (157 / 168 VGPRs, no scratch in the row loop);
+// the packed variants and the ring's STATS variant would spill inside the loop there and stay at 2.
+template <int MODE, bool PACK, bool STATS>
 constexpr int fused_exact_waves() {
-    return (!PACK && !STATS) ? 3 : 2;
+    return (!PACK && !(STATS && MODE == kFusedRing)) ? 3 : 2;
 }
 struct FusedExactArgs {
     const plane_t* inL; const plane_t* inD; plane_t* outL; plane_t* outD;
@@ -660,7 +661,7 @@ struct FusedExactArgs {
 
 template <int MODE, bool PACK = false, bool STATS = false>
 __global__ __launch_bounds__(256)
-__attribute__((amdgpu_waves_per_eu(fused_exact_waves<PACK, STATS>(), fused_exact_waves<PACK, STATS>())))
+__attribute__((amdgpu_waves_per_eu(fused_exact_waves<MODE, PACK, STATS>(), fused_exact_waves<MODE, PACK, STATS>())))
 void step_stream_fused2_exact(FusedExactArgs A) {
     const FusedExactArgs& cold = kernarg_struct<FusedExactArgs>();
     const PhysF32 P2 = with_lum(A.P1, A.lum2);
