@@ -643,10 +643,14 @@ void step_stream_fused2(const plane_t* __restrict__ inL, const plane_t* __restri
 
 // Waves per SIMD of the exact kernels: the plain variants fit 3 waves/SIMD (151-161 VGPRs), and since the constant
 // pairs so do the STATS variants of the overlapped and rotating strips (157 / 168 VGPRs, no scratch in the row loop);
-// the packed variants and the ring's STATS variant would spill inside the loop there and stay at 2.
+// so does the packed variant without STATS (160); the packed STATS variant and the ring's STATS variant would
+// spill inside the loop there and stay at 2.
+#ifndef DW_EXACT_PACK_WAVES
+#define DW_EXACT_PACK_WAVES 3                                      // tuning builds: 2
+#endif
 template <int MODE, bool PACK, bool STATS>
 constexpr int fused_exact_waves() {
-    return (!PACK && !(STATS && MODE == kFusedRing)) ? 3 : 2;
+    return (PACK && STATS) || (STATS && MODE == kFusedRing) ? 2 : (PACK ? DW_EXACT_PACK_WAVES : 3);
 }
 struct FusedExactArgs {
     const plane_t* inL; const plane_t* inD; plane_t* outL; plane_t* outD;
