@@ -425,6 +425,7 @@ def main():
                        "fast": " (float32: per step every cell within 1e-3 and >= 99.98 % of the cell values identical to the "
                                "float64 reference, profiles/r02_fast_tolerance.json)"}.get(args.precision, ""),
                    "plane_format": "binary16 per-mille (lossless for the quantised state)", "kernel": m["kernel"],
+                   "library_build_id": _ffi.load().dw_build_id().decode(),   # content hash of csrc + header + flags
                    "total_worlds": int(all_stats.shape[0]),
                    "parallelism": f"ensemble shard x{n_gpus} (no data-path collective)"},
         "roofline": roofline(m),

@@ -30,6 +30,8 @@ def test_bench_line_follows_the_contract():
     assert d["n_gpus"] == 1 and d["steps"] == 12 and d["warmup"] == 4 and d["scaling"] == "weak"
     assert d["unit"] == "cell-updates/s" and d["higher_is_better"] is True and d["vs_baseline"] is None
     assert "workload" in d["config"] and "model" not in d["config"] and d["config"]["worlds_per_gpu"] == 8
+    from therldaisyworld_amd import build
+    assert d["config"]["library_build_id"] == build.source_id()      # the line names the sources it was measured on
     assert abs(d["value"] - 8 * 4096 * 4096 * 12 / (d["ms_per_step"] * 12e-3)) / d["value"] < 1e-6
     r = d["roofline"]
     assert r["bytes_per_cell_update"] == 4 * r["plane_elem_bytes"] == 8 and r["steps_per_launch"] == 2
