@@ -81,6 +81,9 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for rehearsals)")
+    ap.add_argument("--rank-timeout-s", type=float, default=300.0,
+                    help="self-launched N > 1 runs: kill every rank and exit 124 when the run takes longer")
+    ap.add_argument("--rank-log-dir", default="", help="self-launched N > 1 runs: keep the per-rank logs here")
     ap.add_argument("--no-modes", action="store_true", help="skip the extra run in the other arithmetic mode")
     ap.add_argument("--no-workloads", action="store_true", help="skip the extra C2 measurement")
     ap.add_argument("--selftest-spawn", action="store_true",
@@ -93,28 +96,14 @@ def parse(argv=None):
 # N > 1 without torchrun: launch the ranks ourselves
 # ------------------------------------------------------------------------------------------------
 def spawn_ranks(args, argv):
-    """Parent of a self-launched multi-rank run: start `--gpus N` fresh child processes of this script, one per
-    GPU, with the torchrun environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT) set, wait,
-    relay rank 0's JSON line.  The parent imports neither torch nor the HIP library: a process that has
-    initialised the GPU never replaces itself or forks GPU work."""
-    import socket
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    procs = []
-    for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0, _ = procs[0].communicate()
-    rcs = [p.wait() for p in procs]
-    sys.stdout.write(out0)
-    sys.stdout.flush()
-    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
-    if bad:
-        raise SystemExit(f"bench.py: ranks failed (rank, exit code): {bad}")
-    return 0
+    """Parent of a self-launched multi-rank run: `--gpus N` fresh child processes of this script, one per GPU,
+    supervised by therldaisyworld_amd.ensemble.launch_ranks (torchrun environment; every child polled; the first
+    failing rank terminates the others; `--rank-timeout-s` bounds the whole run; rank logs relayed on failure).
+    The parent imports neither torch nor the HIP library: a process that has initialised the GPU never
+    replaces itself or forks GPU work."""
+    from therldaisyworld_amd.ensemble import launch_ranks
+    return launch_ranks(os.path.abspath(__file__), argv, args.gpus, rank_timeout_s=args.rank_timeout_s,
+                        log_dir=args.rank_log_dir or None)
 
 
 def cpu_baseline(grid: int, budget_s: float = 15.0):
@@ -192,7 +181,13 @@ def selftest_spawn(args):
     import numpy as np
     from therldaisyworld_amd import ensemble
     rank, _, world = ensemble.rank_info()
-    dist = ensemble.init_process_group("gloo") if world > 1 else None
+    # failure rehearsals (tests/test_bench_spawn.py): a rank that dies before the rendezvous / never finishes
+    if os.environ.get("DW_SELFTEST_FAIL_RANK") == str(rank):
+        sys.stderr.write(f"selftest: rank {rank} exits 3 before the rendezvous\n")
+        raise SystemExit(3)
+    if os.environ.get("DW_SELFTEST_HANG_RANK") == str(rank):
+        time.sleep(3600)
+    dist = ensemble.init_process_group("gloo", timeout_s=float(os.environ.get("DW_SELFTEST_DIST_TIMEOUT_S", "120"))) if world > 1 else None
     B = args.worlds or 3
     local = np.arange(B, dtype=np.int64) + rank * B
     if dist is not None:

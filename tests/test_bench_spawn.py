@@ -39,3 +39,56 @@ def test_bench_refuses_a_mismatched_torchrun_environment():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-cpu-baseline"],
                        capture_output=True, text=True, env=env, timeout=300)
     assert p.returncode != 0 and "WORLD_SIZE=1" in (p.stderr + p.stdout)
+
+
+# ---- supervision of the self-launched ranks (ensemble.launch_ranks) -----------------------------------------
+def _spawn(extra, env_extra, timeout=120):
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra)
+    t0 = time.monotonic()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--selftest-spawn", "--backend", "gloo", *extra],
+                       capture_output=True, text=True, env=env, timeout=timeout)
+    return p, time.monotonic() - t0
+
+
+def test_a_rank_that_dies_before_the_rendezvous_ends_the_run_promptly():
+    # rank 1 exits 3 at once; rank 0 would otherwise wait in the rendezvous for its whole timeout
+    p, took = _spawn(["--gpus", "2", "--rank-timeout-s", "200"], {"DW_SELFTEST_FAIL_RANK": "1"})
+    assert p.returncode != 0
+    assert took < 30, f"the parent took {took:.1f} s"
+    assert "(1, 3)" in p.stderr and "rank 1 exits 3" in p.stderr      # who failed, and its own stderr tail
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_rank_zero_failing_is_reported_too():
+    p, took = _spawn(["--gpus", "2", "--rank-timeout-s", "200"], {"DW_SELFTEST_FAIL_RANK": "0"})
+    assert p.returncode != 0 and took < 30 and "(0, 3)" in p.stderr
+
+
+def test_a_rank_that_never_finishes_is_killed_at_the_deadline():
+    # rank 1 sleeps for an hour; rank 0's rendezvous would time out only after 60 s: the deadline comes first
+    p, took = _spawn(["--gpus", "2", "--rank-timeout-s", "6"],
+                     {"DW_SELFTEST_HANG_RANK": "1", "DW_SELFTEST_DIST_TIMEOUT_S": "60"})
+    assert p.returncode == 124, (p.returncode, p.stderr[-1500:])
+    assert 5 < took < 40, f"the parent took {took:.1f} s"
+    assert "--rank-timeout-s" in p.stderr
+
+
+def test_launch_ranks_keeps_logs_on_request(tmp_path):
+    p, _ = _spawn(["--gpus", "2", "--worlds", "2", "--rank-log-dir", str(tmp_path)], {})
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert sorted(os.listdir(tmp_path)) == ["rank0.err", "rank0.out", "rank1.err", "rank1.out"]
+    line = [ln for ln in (tmp_path / "rank0.out").read_text().splitlines() if ln.startswith("{")][0]
+    assert json.loads(line)["total_worlds"] == 4
+
+
+def test_lifespan_sweep_launches_and_gathers_its_own_ranks():
+    # C4's 8-GPU half as one command (tools/lifespan_sweep.py --gpus N); here 2 ranks over gloo, no GPU
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "lifespan_sweep.py"), "--selftest", "--gpus", "2",
+                        "--worlds", "5", "--agents", "3"], capture_output=True, text=True, env=env, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["worlds"] == 10 and d["in_rank_order"]
+    assert abs(d["wall_s"] - 0.02) < 1e-12

@@ -31,9 +31,15 @@ def shard_worlds(total_worlds: int, rank: int, world_size: int):
     return offset, count
 
 
-def init_process_group(backend: str | None = None, device: int | None = None):
+def init_process_group(backend: str | None = None, device: int | None = None, timeout_s: float = 120.0):
     """Initialise torch.distributed from the torchrun environment (no-op for a single process).  `device`: the
-    GPU of this rank when it is not LOCAL_RANK (rehearsals with several ranks on one GPU)."""
+    GPU of this rank when it is not LOCAL_RANK (rehearsals with several ranks on one GPU).  `timeout_s` bounds the
+    rendezvous and every later collective: a rank that never arrives makes the others fail after that long
+    instead of sitting in the store for torch's default 10-30 minutes.  With the nccl (= RCCL) backend the
+    process group is bound to this rank's GPU at creation (`device_id`), so a wrong device ordinal fails here,
+    before any collective."""
+    import datetime
+
     import torch
     import torch.distributed as dist
     rank, local_rank, world = rank_info()
@@ -42,10 +48,133 @@ def init_process_group(backend: str | None = None, device: int | None = None):
     if not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
+        kwargs = {"timeout": datetime.timedelta(seconds=float(timeout_s))}
         if backend == "nccl":
-            torch.cuda.set_device(local_rank if device is None else device)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            dev = local_rank if device is None else device
+            ndev = torch.cuda.device_count()
+            if not (0 <= dev < ndev):
+                raise RuntimeError(f"rank {rank}: GPU {dev} requested but this process sees {ndev} device(s)")
+            torch.cuda.set_device(dev)
+            kwargs["device_id"] = torch.device("cuda", dev)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kwargs)
     return dist
+
+
+# ------------------------------------------------------------------------------------------------
+# self-launched ranks (the reference's launcher analogue: daisy/evo/sges.py:215-245, 401-412)
+# ------------------------------------------------------------------------------------------------
+def _tail(path: str, nbytes: int = 3000) -> str:
+    try:
+        with open(path, "rb") as f:
+            f.seek(0, os.SEEK_END)
+            f.seek(max(0, f.tell() - nbytes))
+            return f.read().decode("utf-8", "replace")
+    except OSError:
+        return ""
+
+
+def launch_ranks(script: str, argv, n_ranks: int, rank_timeout_s: float = 300.0, log_dir: str | None = None,
+                 extra_env=None, poll_s: float = 0.1) -> int:
+    """Start `n_ranks` fresh child processes of `script` (one per GPU) with the torchrun environment set
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT), SUPERVISE them, relay rank 0's
+    stdout, and return the exit code for the parent (0 only if every rank exited 0).
+
+    * every child is polled; the first non-zero exit terminates the others (SIGTERM, SIGKILL after 5 s) - a rank
+      that dies before the rendezvous must not leave the rest waiting in it;
+    * `rank_timeout_s` bounds the whole run: past it every child is killed and the parent returns 124;
+    * all ranks log to files (`log_dir`, default a fresh temporary directory): stdout of rank 0 is relayed when
+      the run ends, the stderr tail of every failed rank is relayed to the parent's stderr;
+    * a rendezvous port that was taken between its selection and rank 0's bind ("address already in use") gets
+      ONE fresh attempt on another port.
+
+    The parent never imports torch or the HIP library and nothing is re-exec'd: children are fresh processes,
+    and only those are ever signalled (by the exact process group each was started in)."""
+    import signal
+    import socket
+    import subprocess
+    import sys
+    import tempfile
+    import time
+
+    own_dir = log_dir is None
+    if own_dir:
+        log_dir = tempfile.mkdtemp(prefix="dw_ranks_")
+    os.makedirs(log_dir, exist_ok=True)
+
+    def stop(procs):
+        for p in procs:
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, signal.SIGTERM)            # the child's own session: it and what it started
+                except (ProcessLookupError, PermissionError):
+                    pass
+        t_end = time.monotonic() + 5.0
+        for p in procs:
+            while p.poll() is None and time.monotonic() < t_end:
+                time.sleep(0.05)
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, signal.SIGKILL)
+                except (ProcessLookupError, PermissionError):
+                    pass
+                p.wait()
+
+    def attempt(tag):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        procs, files = [], []
+        for r in range(n_ranks):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=str(port),
+                       HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+            env.update(extra_env or {})
+            out = open(os.path.join(log_dir, f"rank{r}{tag}.out"), "wb")
+            err = open(os.path.join(log_dir, f"rank{r}{tag}.err"), "wb")
+            files += [out, err]
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(script), *argv], env=env, stdout=out,
+                                          stderr=err, start_new_session=True))
+        deadline = time.monotonic() + float(rank_timeout_s)
+        code, why = 0, ""
+        try:
+            while True:
+                rcs = [p.poll() for p in procs]
+                bad = [(r, rc) for r, rc in enumerate(rcs) if rc not in (None, 0)]
+                if bad:
+                    code, why = 1, f"ranks failed (rank, exit code): {bad}; the other ranks were terminated"
+                    break
+                if all(rc == 0 for rc in rcs):
+                    break
+                if time.monotonic() > deadline:
+                    code = 124
+                    why = (f"ranks still running after --rank-timeout-s {rank_timeout_s:g}: "
+                           f"{[r for r, rc in enumerate(rcs) if rc is None]}; all ranks were killed")
+                    break
+                time.sleep(poll_s)
+        finally:
+            stop(procs)
+            for f in files:
+                f.close()
+        return code, why, [p.returncode for p in procs]
+
+    tag = ""
+    code, why, rcs = attempt(tag)
+    if code == 1 and any("ddress already in use" in _tail(os.path.join(log_dir, f"rank{r}.err")) for r in range(n_ranks)):
+        tag = ".retry"
+        code, why, rcs = attempt(tag)
+    sys.stdout.write(_tail(os.path.join(log_dir, f"rank0{tag}.out"), 1 << 22))
+    sys.stdout.flush()
+    if code:
+        sys.stderr.write(f"launch_ranks: {why}\n")
+        for r, rc in enumerate(rcs):
+            if rc != 0:
+                sys.stderr.write(f"--- rank {r} (exit {rc}) stderr tail [{log_dir}/rank{r}{tag}.err] ---\n")
+                sys.stderr.write(_tail(os.path.join(log_dir, f"rank{r}{tag}.err")) + "\n")
+        sys.stderr.flush()
+    elif own_dir:
+        import shutil
+        shutil.rmtree(log_dir, ignore_errors=True)
+    return code
 
 
 def gather_per_world(local: np.ndarray, counts=None, device=None) -> np.ndarray:

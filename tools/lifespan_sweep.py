@@ -8,8 +8,9 @@ convention shifted per rank (seed + rank); there is no communication while the e
 the per-world lifespans are gathered once (RCCL all-gather of a few kB) and rank 0 prints the table.
 
     python tools/lifespan_sweep.py --worlds 1000 --dim 8                       # one GPU
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \\
-        tools/lifespan_sweep.py --worlds 1000 --dim 256                        # C4: 8 x 1000 worlds of 256x256
+    python tools/lifespan_sweep.py --gpus 8 --worlds 1000 --dim 256            # C4: 8 x 1000 worlds of 256x256
+                                                                               # (starts and supervises its 8 ranks:
+                                                                               # ensemble.launch_ranks; torchrun works too)
 
 The step loop is device-resident in chunks (`dw_run_episode`): one launch per chunk for dim*dim <= 4096,
 back-to-back launches without host round trips for larger worlds.  Measured on one MI355X, 1000 worlds,
@@ -29,6 +30,32 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
+def selftest(args, rank, world):
+    """Every rank fabricates the lifespans of its block of worlds from their GLOBAL ids; the gathered table
+    must list them in rank order, exactly once (tests/test_bench_spawn.py)."""
+    from therldaisyworld_amd import ensemble
+    dist = ensemble.init_process_group("gloo") if world > 1 else None
+    B, N = args.worlds, args.agents
+    ids = rank * B + np.arange(B)
+    done_at = (400 + ids % 7).astype(int)
+    agents_done_at = (100 + (ids[:, None] + np.arange(N)[None]) % 5).astype(int)[..., None]
+    wall = 0.01 * (rank + 1)
+    if dist is not None:
+        done_at = ensemble.gather_per_world(done_at)
+        agents_done_at = ensemble.gather_per_world(agents_done_at)
+        wall = ensemble.max_over_ranks(wall)
+    if rank == 0:
+        expect = 400 + np.arange(world * B) % 7
+        print(json.dumps({"sweep": "selftest", "n_gpus": world, "worlds": int(done_at.shape[0]),
+                          "in_rank_order": bool(np.array_equal(done_at, expect)),
+                          "biosphere_lifespan_mean": float(done_at.mean()),
+                          "agent_lifespan_mean": float(agents_done_at.mean()), "wall_s": wall}))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--worlds", type=int, default=1000, help="worlds per rank and policy")
@@ -43,17 +70,31 @@ def main():
                          "device-side initial state with the same distribution (reset_synthetic)")
     ap.add_argument("--albedos", default="default", choices=["default", "neutral"],
                     help="neutral: albedo_light = albedo_dark = 0.5 (the notebook's control case)")
+    ap.add_argument("--gpus", type=int, default=0,
+                    help="start this many ranks (one per GPU) and supervise them; 0: run as the single process / the "
+                         "torchrun rank this process already is")
+    ap.add_argument("--rank-timeout-s", type=float, default=900.0)
+    ap.add_argument("--selftest", action="store_true",
+                    help="CPU rehearsal of the multi-rank plumbing (launch, rendezvous, per-world gather in rank order, "
+                         "max-over-ranks, rank-0 table) with synthetic lifespans: no GPU is touched")
     args = ap.parse_args()
 
     from therldaisyworld_amd import ensemble
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(ensemble.launch_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus,
+                                               rank_timeout_s=args.rank_timeout_s))
     rank, local_rank, world = ensemble.rank_info()
+    if args.gpus > 1 and args.gpus != world:
+        raise SystemExit(f"lifespan_sweep.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.selftest:
+        return selftest(args, rank, world)
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("lifespan_sweep.py needs a GPU: the product path has no CPU fallback")
     if os.environ.get("DW_BENCH_ALL_RANKS_ON_DEVICE0"):
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    dist = ensemble.init_process_group(args.backend) if world > 1 else None
+    dist = ensemble.init_process_group(args.backend, device=local_rank) if world > 1 else None
 
     import therldaisyworld_amd as amd
     from therldaisyworld_amd.harness import simulate_lifespan
