@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define DW_ABI_VERSION 2
+#define DW_ABI_VERSION 3
 
 /* ---- error codes ---------------------------------------------------------------------------- */
 enum {
@@ -248,6 +248,24 @@ int dw_forward_f64(dw_handle* h, const double* light, const double* dark, double
  * calculate_albedo (ref :377-394) and calculate_daisy_density (ref :423-432) are built from; the drop-in's
  * stand-alone calculate_* methods call it.  Does not touch the handle's state. */
 int dw_conv3x3_f64(dw_handle* h, const double* plane, const double kernel[9], double* out);
+
+/* The stages of forward() as stand-alone float64 maps on caller data, evaluated on the device (the drop-in's
+ * calculate_* methods; forward() and step() use the fused kernels, never these).  `in` / `out`: host arrays of
+ * whole planes, [plane][B][H][W] float64; `L`: the luminosity of the pass (stage 3); `kernel`: the nine row-major
+ * weights of the stage's 3x3 toroidal convolution (stages 1, 2; ft_convolve, ref daisy/nn/functional.py:12-49).
+ *   DW_STAGE_ALBEDO       ref calculate_albedo :377-394         in  bare (ignored: recomputed as p - l - d, ref :381), light, dark
+ *                                                                out local albedo, adjacent albedo, bare
+ *   DW_STAGE_DENSITY      ref calculate_daisy_density :423-432  in  light, dark           out density_light, density_dark
+ *   DW_STAGE_TEMPERATURE  ref calculate_temperature :396-421    in  local, adjacent albedo out temp_effective, temp, temp_light, temp_dark
+ *   DW_STAGE_GROWTH_RATE  ref calculate_growth_rate :340-348    in  temp, temp_light, temp_dark out beta, beta_l, beta_d
+ *   DW_STAGE_GROWTH       ref calculate_growth :350-375         in  beta_l, beta_d, density_light, density_dark out growth_light, growth_dark
+ * Does not touch the handle's state. */
+#define DW_STAGE_ALBEDO 1
+#define DW_STAGE_DENSITY 2
+#define DW_STAGE_TEMPERATURE 3
+#define DW_STAGE_GROWTH_RATE 4
+#define DW_STAGE_GROWTH 5
+int dw_stage_f64(dw_handle* h, int stage, const double* in, double* out, double L, const double kernel[9]);
 
 /* Observations (ref get_obs :246-263): [B][N][7][3][3] float64 for the handle's agents, taken from
  * the current grid exactly as dw_download_grid would materialise it, times the neighbourhood mask. */

@@ -304,3 +304,50 @@ def test_fitness_bookkeeping_per_chunk_equals_the_reference_loop(chunk, p_done):
         sl = slice(m * wpm, (m + 1) * wpm)
         assert np.array_equal(acc["done_at"][sl], d_at) and np.array_equal(acc["total_steps"][sl], tot)
         assert acc["sum_reward"][m] == s
+
+
+def test_pair_allocation_is_all_or_nothing(tmp_path):
+    """when the second of two plane allocations fails, neither pointer may stay set - the next call
+    must report the failure again (or retry), never find one plane and launch on a null second one.  The helper
+    has no HIP types (csrc/dw_host_util.hpp), so it is exercised here with a mock allocator under g++."""
+    import shutil
+    import subprocess
+    src = tmp_path / "pair.cpp"
+    src.write_text(r'''
+#include <cstdio>
+#include <cstdlib>
+#include "dw_host_util.hpp"
+static int n_alloc = 0, n_free = 0, fail_on = 0;
+int main() {
+    auto alloc = [](void** p, size_t n) { if (++n_alloc == fail_on) { *p = (void*)0x1; return 7; } *p = std::malloc(n); return *p ? 0 : 1; };
+    auto release = [](void* p) { ++n_free; std::free(p); return 0; };
+    void *a = nullptr, *b = nullptr;
+    fail_on = 2;                                            // the SECOND allocation fails
+    int rc = dw::alloc_pair_all_or_nothing(&a, &b, 64, alloc, release);
+    if (rc != 7 || a || b || n_free != 1) { std::printf("after failure: rc=%d a=%p b=%p frees=%d\n", rc, a, b, n_free); return 1; }
+    fail_on = 3;                                            // the retry fails at once: still nothing held
+    rc = dw::alloc_pair_all_or_nothing(&a, &b, 64, alloc, release);
+    if (rc != 7 || a || b) return 2;
+    fail_on = 0;
+    rc = dw::alloc_pair_all_or_nothing(&a, &b, 64, alloc, release);
+    if (rc != 0 || !a || !b) return 3;
+    void *a0 = a, *b0 = b;
+    const int before = n_alloc;
+    rc = dw::alloc_pair_all_or_nothing(&a, &b, 64, alloc, release);   // both present: nothing happens
+    if (rc != 0 || a != a0 || b != b0 || n_alloc != before) return 4;
+    void* lone = std::malloc(8);                            // a half-allocated pair left behind by older code
+    void* none = nullptr;
+    const int frees = n_free;
+    rc = dw::alloc_pair_all_or_nothing(&lone, &none, 64, alloc, release);
+    if (rc != 0 || !lone || !none || n_free != frees + 1) return 5;
+    std::puts("ok");
+    return 0;
+}
+''')
+    gxx = shutil.which("g++")
+    assert gxx
+    exe = tmp_path / "pair"
+    subprocess.check_call([gxx, "-std=c++17", "-Wall", "-I", os.path.join(ROOT, "therldaisyworld_amd", "csrc"), str(src),
+                           "-o", str(exe)])
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.strip() == "ok", (out.returncode, out.stdout)

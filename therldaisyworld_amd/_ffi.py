@@ -14,11 +14,13 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DW_LIB", os.path.join(_HERE, "libdaisyworld_hip.so"))   # DW_LIB: tuning builds
 
-DW_ABI_VERSION = 2
+DW_ABI_VERSION = 3
 DW_OK, DW_EINVAL, DW_ENODEVICE, DW_ENOMEM, DW_EHIP, DW_ESTATE = 0, -1, -2, -3, -4, -5
 PRECISION = {"exact": 0, "fast": 1, "f64": 2}
 STATE_CURRENT, STATE_PREVIOUS = 0, 1
 POLICY_ARGMAX, POLICY_ARGMIN, POLICY_ZEROS, POLICY_TABLE = 0, 1, 2, 3
+STAGE_ALBEDO, STAGE_DENSITY, STAGE_TEMPERATURE, STAGE_GROWTH_RATE, STAGE_GROWTH = 1, 2, 3, 4, 5
+STAGE_IO = {1: (3, 3), 2: (2, 2), 3: (2, 4), 4: (3, 3), 5: (4, 2)}          # stage -> (planes in, planes out)
 
 
 class DaisyHipError(RuntimeError):
@@ -77,6 +79,7 @@ SIGNATURES = {
     "dw_update_agents": (C.c_int, [_vp, _pi, _i32, _i32]),
     "dw_forward_f64": (C.c_int, [_vp, _pd, _pd, _dbl, _pd, _pd, _pd, _pd, _pd]),
     "dw_conv3x3_f64": (C.c_int, [_vp, _pd, _pd, _pd]),
+    "dw_stage_f64": (C.c_int, [_vp, C.c_int, _pd, _pd, _dbl, _pd]),
     "dw_get_obs": (C.c_int, [_vp, _dbl, _pd]),
     "dw_get_reward_done": (C.c_int, [_vp, _pd, _pu8]),
     "dw_reduce": (C.c_int, [_vp, C.POINTER(DwWorldStats)]),

@@ -17,6 +17,7 @@
 
 #include "../../include/daisyworld_hip.h"
 #include "dw_kernels.hpp"
+#include "dw_host_util.hpp"
 
 using namespace dw;
 
@@ -107,7 +108,8 @@ struct dw_handle {
     unsigned char* done_d = nullptr;  // [B][N]
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t evf0 = nullptr, evf1 = nullptr;   // around the fused launches of the last dw_step_n call
-    int fused_launches = 0;           // ... and how many there were (dw_last_step_n_timing)
+    int fused_launches = 0;           // ... and how many there were (dw_last_step_n_timing); 0 unless BOTH events
+                                      // of that call were recorded (an error return in between leaves 0)
     StatsDev* side_stats = nullptr;   // reductions of dw_forward_f64's side computation (not the handle's)
     unsigned char* pinned = nullptr;  // page-locked host staging of dw_env_step (actions in, obs/reward/done out)
     size_t pinned_bytes = 0;
@@ -154,11 +156,35 @@ static void release_unquantised(dw_handle* h) {
     h->U32L = nullptr; h->U32D = nullptr;
 }
 
+// The two planes of an un-quantised state come and go together (dw_host_util.hpp): a failed second allocation
+// leaves NEITHER, so a retry on the same handle reports DW_ENOMEM again instead of launching on a null plane.
+// DW_TEST_FAIL_PAIR_ALLOC=<n> (tests): the second allocation of the next n pairs fails with out-of-memory.
+static int alloc_plane_pair(void** a, void** b, size_t bytes) {
+    static int fail_left = [] { const char* e = std::getenv("DW_TEST_FAIL_PAIR_ALLOC"); return e ? std::atoi(e) : 0; }();
+    int calls = 0;
+    hipError_t last = hipSuccess;
+    const int rc = alloc_pair_all_or_nothing(
+        a, b, bytes,
+        [&](void** p, size_t n) {
+            if (++calls == 2 && fail_left > 0) { --fail_left; last = hipErrorOutOfMemory; *p = nullptr; return 1; }
+            last = hipMalloc(p, n);
+            return last == hipSuccess ? 0 : 1;
+        },
+        [](void* p) { return hipFree(p) == hipSuccess ? 0 : 1; });
+    if (rc == 0) return DW_OK;
+    (void)hipGetLastError();                                     // the failed hipMalloc must not poison later checks
+    return fail(last == hipErrorOutOfMemory ? DW_ENOMEM : DW_EHIP, "allocating two planes of %zu bytes failed: %s",
+                bytes, hipGetErrorString(last));
+}
+
 static int ensure_u32(dw_handle* h) {
-    if (h->U32L) return DW_OK;
-    HIPCHK(hipMalloc(&h->U32L, sizeof(float) * h->cells));
-    HIPCHK(hipMalloc(&h->U32D, sizeof(float) * h->cells));
-    return DW_OK;
+    return alloc_plane_pair(reinterpret_cast<void**>(&h->U32L), reinterpret_cast<void**>(&h->U32D),
+                            sizeof(float) * h->cells);
+}
+
+static int ensure_f64(dw_handle* h) {
+    return alloc_plane_pair(reinterpret_cast<void**>(&h->L64), reinterpret_cast<void**>(&h->D64),
+                            sizeof(double) * h->cells);
 }
 
 static int run_episode_impl(dw_handle* h, int32_t nsteps, const double* L_schedule, int policy_mode,
@@ -802,10 +828,7 @@ static int refresh_stats(dw_handle* h) {
 int dw_upload_state_f64(dw_handle* h, const double* light, const double* dark) {
     NEED(h && light && dark, DW_EINVAL, "null argument");
     HIPCHK(hipSetDevice(h->prm.device));
-    if (!h->L64) {
-        HIPCHK(hipMalloc(&h->L64, sizeof(double) * h->cells));
-        HIPCHK(hipMalloc(&h->D64, sizeof(double) * h->cells));
-    }
+    if (int arc = ensure_f64(h)) return arc;
     HIPCHK(hipMemcpyAsync(h->L64, light, sizeof(double) * h->cells, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->D64, dark, sizeof(double) * h->cells, hipMemcpyHostToDevice, h->stream));
     h->unq_kind = UNQ_F64;
@@ -1150,18 +1173,25 @@ int dw_step_n(dw_handle* h, int32_t nsteps, double* L_io, double dL, double min_
         // wide grids: pairs of steps share one HBM round trip; the last one or two steps are ordinary launches
         // so that the retained previous state is the true predecessor.  HIP events around the run of fused
         // launches feed dw_last_step_n_timing (the dominant kernel's duration, measured on its own stream).
+        // The first fused launch ends the life of an un-quantised PREVIOUS state (after it the retained state is two
+        // steps back anyway): drop it here, so that release_unquantised's synchronise + hipFree of 128 GiB at the
+        // north-star shape happen in front of the timed window and not inside it.
+        if (h->unq == OWN_PREV) { h->unq = OWN_NONE; h->stepped = false; }
+        release_unquantised(h);
         HIPCHK(hipEventRecord(h->evf0, h->stream));
+        int launched = 0;
         while (nsteps - s0 >= 3) {
             const double L1 = L;
             advance();
             const double L2 = L;
             advance();
             int rc = launch_forward_fused2(h, L1, L2);
-            if (rc) return rc;
+            if (rc) return rc;                  // fused_launches stays 0: no timing of a run that was cut short
             s0 += 2;
-            h->fused_launches += 1;
+            launched += 1;
         }
         HIPCHK(hipEventRecord(h->evf1, h->stream));
+        h->fused_launches = launched;           // valid only now that evf1 is recorded
     }
     for (int s = s0; s < nsteps; ++s) {
         int rc;
@@ -1264,6 +1294,39 @@ int dw_conv3x3_f64(dw_handle* h, const double* plane, const double kernel[9], do
     hipLaunchKernelGGL(conv3x3_f64, g, dim3(256), 0, h->stream, d_in, d_out, p.height, p.width, K);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out, d_out, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    guard.disarm();
+    return DW_OK;
+}
+
+int dw_stage_f64(dw_handle* h, int stage, const double* in, double* out, double L, const double kernel[9]) {
+    NEED(h && in && out, DW_EINVAL, "null argument");
+    NEED(stage >= kStageAlbedo && stage <= kStageGrowth, DW_EINVAL, "bad stage %d", stage);
+    NEED(kernel || stage > kStageDensity, DW_EINVAL, "the stencil stages need their 3x3 kernel");
+    const dw_params& p = h->prm;
+    HIPCHK(hipSetDevice(p.device));
+    const size_t n = h->cells, nin = (size_t)stage_inputs(stage), nout = (size_t)stage_outputs(stage);
+    int rc = ensure_scratch(h, sizeof(double) * (nin + nout) * n);
+    if (rc) return rc;
+    double* d_in = h->scratch;
+    double* d_out = d_in + nin * n;
+    Kernel9 K{};
+    if (kernel) for (int i = 0; i < 9; ++i) K.k[i] = kernel[i];
+    const PhysF64 P = make_f64(p, L);
+    SyncOnExit guard(h->stream);                              // `in` / `out` are the caller's
+    HIPCHK(hipMemcpyAsync(d_in, in, sizeof(double) * nin * n, hipMemcpyHostToDevice, h->stream));
+    const dim3 g((unsigned)((p.height * p.width + 255) / 256), (unsigned)p.batch);
+#define DW_STAGE(S) hipLaunchKernelGGL((stage_f64<S>), g, dim3(256), 0, h->stream, d_in, d_out, p.batch, p.height, p.width, P, K)
+    switch (stage) {
+        case kStageAlbedo: DW_STAGE(kStageAlbedo); break;
+        case kStageDensity: DW_STAGE(kStageDensity); break;
+        case kStageTemperature: DW_STAGE(kStageTemperature); break;
+        case kStageGrowthRate: DW_STAGE(kStageGrowthRate); break;
+        default: DW_STAGE(kStageGrowth); break;
+    }
+#undef DW_STAGE
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, d_out, sizeof(double) * nout * n, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     guard.disarm();
     return DW_OK;

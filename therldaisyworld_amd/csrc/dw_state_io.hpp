@@ -217,6 +217,85 @@ __global__ __launch_bounds__(256) void conv3x3_f64(const double* __restrict__ x,
     out[woff + cell] = acc;
 }
 
+// stage_f64 — the stages of the reference's forward() as stand-alone float64 maps on CALLER data (the drop-in's
+// calculate_* methods; forward() / step() never use them: they run the fused map).  Planes are [plane][B][H][W]
+// float64, one thread per cell.  K9 = the 3x3 kernel of the stencil stages, taps in the order of conv3x3_f64.
+//   1 albedo       ref :377-394  in  bare (ignored), light, dark   out local albedo, adjacent albedo, bare = p - l - d
+//   2 density      ref :423-432  in  light, dark                   out density_light, density_dark
+//   3 temperature  ref :396-421  in  local albedo, adjacent albedo out T_effective, T, T_light, T_dark
+//   4 growth rate  ref :340-348  in  T, T_light, T_dark            out beta, beta_l, beta_d
+//   5 growth       ref :350-375  in  beta_l, beta_d, dens_l, dens_d out growth_light, growth_dark
+enum { kStageAlbedo = 1, kStageDensity = 2, kStageTemperature = 3, kStageGrowthRate = 4, kStageGrowth = 5 };
+__host__ __device__ constexpr int stage_inputs(int s) { return s == 1 ? 3 : (s == 2 ? 2 : (s == 3 ? 2 : (s == 4 ? 3 : 4))); }
+__host__ __device__ constexpr int stage_outputs(int s) { return s == 1 ? 3 : (s == 2 ? 2 : (s == 3 ? 4 : (s == 4 ? 3 : 2))); }
+
+template <typename F>
+__device__ __forceinline__ double torus_conv9(const Kernel9& K, int i, int j, int H, int W, F value_at) {
+    double acc = 0.0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const int ii = (i - (a - 1) + H) % H;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            if (K.k[a * 3 + c] == 0.0) continue;
+            const int jj = (j - (c - 1) + W) % W;
+            acc += K.k[a * 3 + c] * value_at((size_t)ii * W + jj);
+        }
+    }
+    return acc;
+}
+
+template <int STAGE>
+__global__ __launch_bounds__(256) void stage_f64(const double* __restrict__ in, double* __restrict__ out, int B, int H,
+                                                 int W, PhysF64 P, Kernel9 K) {
+    const int b = blockIdx.y;
+    const int cell = blockIdx.x * 256 + threadIdx.x;
+    if (cell >= H * W) return;
+    const size_t plane = (size_t)B * H * W, woff = (size_t)b * H * W, o = woff + cell;
+    const int i = cell / W, j = cell - i * W;
+    if constexpr (STAGE == kStageAlbedo) {
+        const double* l = in + plane + woff;
+        const double* d = in + 2 * plane + woff;
+        const double bare = P.p - l[cell] - d[cell];
+        double local = 0.0, adjacent = 0.0;                     // accumulated over bare, light, dark in this order
+        local += P.ab * bare;
+        adjacent += P.ab * torus_conv9(K, i, j, H, W, [&](size_t q) { return P.p - l[q] - d[q]; });
+        local += P.al * l[cell];
+        adjacent += P.al * torus_conv9(K, i, j, H, W, [&](size_t q) { return l[q]; });
+        local += P.ad * d[cell];
+        adjacent += P.ad * torus_conv9(K, i, j, H, W, [&](size_t q) { return d[q]; });
+        out[o] = local;
+        out[plane + o] = adjacent;
+        out[2 * plane + o] = bare;
+    } else if constexpr (STAGE == kStageDensity) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const double* x = in + c * plane + woff;
+            out[c * plane + o] = torus_conv9(K, i, j, H, W, [&](size_t q) { return x[q]; });
+        }
+    } else if constexpr (STAGE == kStageTemperature) {
+        const double Al = in[o], A = in[plane + o];
+        const double Te = pow((P.S * P.L * (1.0 - A)) / P.sigma, 0.25);
+        const double T = pow(P.q * (A - Al) + dw_pow4(Te), 0.25);
+        const double T4 = dw_pow4(T);
+        out[o] = Te;
+        out[plane + o] = T;
+        out[2 * plane + o] = pow(P.q2 * (Al - P.al) + T4, 0.25);
+        out[3 * plane + o] = pow(P.q2 * (Al - P.ad) + T4, 0.25);
+    } else if constexpr (STAGE == kStageGrowthRate) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const double dT = P.To - in[c * plane + o];
+            out[c * plane + o] = 1.0 - P.g * (dT * dT);
+        }
+    } else {
+        const double bl = in[o], bd = in[plane + o], kl = in[2 * plane + o], kd = in[3 * plane + o];
+        const double kb = P.p - kl - kd;
+        out[o] = kl * (kb * bl - P.gamma);
+        out[plane + o] = kd * (kb * bd - P.gamma);
+    }
+}
+
 // plane conversions
 // natural-unit float32 upload -> un-quantised per-mille float32 (in place allowed)
 __global__ void f32nat_to_permille(const float* __restrict__ in, float* __restrict__ out, size_t n) {

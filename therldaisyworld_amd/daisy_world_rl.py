@@ -10,8 +10,9 @@ the config helpers (:94-171), and the attributes callers read (``grid``, ``temp`
 
 What stays on the host: the legacy NumPy RNG draws (same global stream, same call order as the
 reference, so the same ``np.random.seed`` gives the same worlds), the scalar luminosity recurrence,
-and bookkeeping.  Everything per-cell or per-agent runs in HIP kernels; there is no CPU compute path,
-and construction fails if the HIP library or a gfx950 device is missing.
+and bookkeeping.  Everything per-cell or per-agent runs in HIP kernels - also the stand-alone stage methods
+(`calculate_*`: one float64 device call each, dw_stage_f64); there is no CPU compute path, and construction
+fails if the HIP library or a gfx950 device is missing.
 """
 from __future__ import annotations
 
@@ -400,68 +401,65 @@ class RLDaisyWorld:
         return new_grid
 
     # ------------------------------------------------------------------------------------------
-    # the stages of forward() as stand-alone methods (ref :340-432).  forward() / step() never call these:
-    # the device evaluates the fused map.  The two stencil stages run their convolutions on the device
-    # (dw_conv3x3_f64: the direct form of ft_convolve); the three pointwise stages are the reference's float64
-    # expressions on the caller's arrays.  Like the reference they refresh temp / beta / growth.
+    # the stages of forward() as stand-alone methods (ref :340-432).  forward() / step() never call these (the
+    # device evaluates the fused map); each is ONE device call on the caller's arrays (dw_stage_f64: float64, the
+    # reference's staging), and like the reference's stages they overwrite the temp / beta / growth attributes.
     # ------------------------------------------------------------------------------------------
-    def _conv(self, x, kernel):
-        """ft_convolve(x, kernel) (ref nn/functional.py:12-49) for x of shape (B,1,H,W)."""
-        return self._ensure_engine().conv3x3(np.asarray(x, dtype=np.float64)[:, 0], np.asarray(kernel)[0, 0])[:, None]
+    def _stage(self, stage, planes, kernel=None):
+        """Run one stage on the device: `planes` are (B,H,W) views; results come back as (B,1,H,W) arrays."""
+        outs = self._ensure_engine().stage(stage, [np.asarray(x, dtype=np.float64) for x in planes], self.L,
+                                           None if kernel is None else np.asarray(kernel)[0, 0])
+        return [o[:, None] for o in outs]
+
+    @staticmethod
+    def _channels(x, n):
+        """The first n channels of a (B,>=n,H,W) array, or n separate (B,1,H,W) / (B,H,W) arrays, as (B,H,W) views."""
+        x = np.asarray(x)
+        return [x[:, c] for c in range(n)]
 
     def calculate_albedo(self, groundcover):
-        """ref :377-394: (local_albedo, adjacent_albedo), both (B,1,H,W); rewrites channel 0 in place (:381)."""
-        groundcover[:, 0, ...] = self.p - groundcover[:, 1, :, :] - groundcover[:, 2, :, :]
-        local_albedo = np.zeros((self.batch_size, 1, self.dim, self.dim))
-        adjacent_albedo = np.zeros((self.batch_size, 1, self.dim, self.dim))
-        for ii, albedo in enumerate([self.albedo_bare, self.albedo_light, self.albedo_dark]):
-            local_albedo += albedo * groundcover[:, ii:ii + 1, :, :]
-            adjacent_albedo += albedo * self._conv(groundcover[:, ii:ii + 1, :, :], self.adjacent_albedo_kernel)
-        return local_albedo, adjacent_albedo
+        """ref :377-394 -> (local_albedo, adjacent_albedo), (B,1,H,W) each; channel 0 of the argument is rewritten
+        with the bare fraction the pass works with (ref :381)."""
+        local, adjacent, bare = self._stage(_ffi.STAGE_ALBEDO, self._channels(groundcover, 3), self.adjacent_albedo_kernel)
+        groundcover[:, 0] = bare[:, 0]
+        return local, adjacent
 
     def calculate_daisy_density(self, local_daisies):
-        """ref :423-432: (B,2,H,W) densities of light and dark daisies under the daisy kernel."""
-        daisy_density = np.zeros((self.batch_size, 2, self.dim, self.dim))
-        for jj in range(self.n_daisies):
-            daisy_density[:, jj:jj + 1, :, :] = self._conv(local_daisies[:, jj:jj + 1, :, :], self.daisy_kernel)
-        return daisy_density
+        """ref :423-432 -> (B,2,H,W): light and dark cover under the daisy kernel."""
+        return np.concatenate(self._stage(_ffi.STAGE_DENSITY, self._channels(local_daisies, 2), self.daisy_kernel), axis=1)
 
     def calculate_temperature(self, local_albedo, adjacent_albedo):
-        """ref :396-421: (temp, temp_light, temp_dark); refreshes temp_effective / temp* / dead_temp."""
-        Al, A = local_albedo, adjacent_albedo
-        temp_effective = ((self.S * self.L * (1 - A)) / self.sigma) ** (1 / 4)
-        temp = (self.q * (A - Al) + temp_effective ** 4) ** (1 / 4)
-        light_temp = (self.q2 * (Al - self.albedo_light) + temp ** 4) ** (1 / 4)
-        dark_temp = (self.q2 * (Al - self.albedo_dark) + temp ** 4) ** (1 / 4)
-        self._L_pass = self.L                                 # dead_temp follows the luminosity of this pass
-        self._stage_caches(temp_effective=temp_effective, temp=temp, temp_light=light_temp, temp_dark=dark_temp)
-        return temp, light_temp, dark_temp
+        """ref :396-421 -> (temp, temp_light, temp_dark); also sets temp_effective and moves dead_temp to this
+        pass's luminosity."""
+        planes = [np.asarray(local_albedo)[:, 0], np.asarray(adjacent_albedo)[:, 0]]
+        effective, temp, temp_light, temp_dark = self._stage(_ffi.STAGE_TEMPERATURE, planes)
+        self._L_pass = self.L
+        self._stage_caches(temp_effective=effective, temp=temp, temp_light=temp_light, temp_dark=temp_dark)
+        return temp, temp_light, temp_dark
 
     def calculate_growth_rate(self, temp, temp_l, temp_d):
-        """ref :340-348."""
-        beta = 1 - self.g * (self.temp_optimal - temp) ** 2
-        beta_l = 1 - self.g * (self.temp_optimal - temp_l) ** 2
-        beta_d = 1 - self.g * (self.temp_optimal - temp_d) ** 2
-        self._stage_caches(beta=beta, beta_l=beta_l, beta_d=beta_d)
-        return beta, beta_l, beta_d
+        """ref :340-348 -> (beta, beta_l, beta_d)."""
+        betas = self._stage(_ffi.STAGE_GROWTH_RATE, [np.asarray(t)[:, 0] for t in (temp, temp_l, temp_d)])
+        self._stage_caches(beta=betas[0], beta_l=betas[1], beta_d=betas[2])
+        return tuple(betas)
 
     def calculate_growth(self, beta, beta_l, beta_d, daisy_density):
-        """ref :350-375 (the branch that uses beta is dead code in the reference, :362-364)."""
-        a_l = daisy_density[:, 0, :, :]
-        a_d = daisy_density[:, 1, :, :]
-        a_b = self.p - a_l - a_d
-        growth = np.zeros_like(daisy_density)
-        growth[:, 0, ...] = a_l * (a_b * beta_l.squeeze() - self.gamma)
-        growth[:, 1, ...] = a_d * (a_b * beta_d.squeeze() - self.gamma)
+        """ref :350-375 -> (B,2,H,W) growth of light and dark; `beta` is accepted and unused, as in the reference
+        (the branch that reads it is dead code there, :362-364)."""
+        planes = [np.asarray(beta_l)[:, 0], np.asarray(beta_d)[:, 0], *self._channels(daisy_density, 2)]
+        growth = np.concatenate(self._stage(_ffi.STAGE_GROWTH, planes), axis=1)
         self._stage_caches(growth=growth)
         return growth
 
     def _stage_caches(self, **values):
-        """The stand-alone stages overwrite the side-effect caches one by one, as the reference's do."""
+        """The stand-alone stages overwrite the side-effect caches one by one, as the reference's do: the others
+        keep the values of the last physics pass (materialised first), or stay unset when there has been none."""
         if not self._caches:
             try:
-                self._cache("temp")                           # materialise the others before overriding some
-            except Exception:
+                self._cache("temp")
+            except _ffi.DaisyHipError as e:
+                if e.code != _ffi.DW_ESTATE:                  # "no state yet" is the only expected reason
+                    raise
                 self._caches = {}
         self._caches = dict(self._caches, **values)
 

@@ -206,6 +206,19 @@ class Engine:
         self._check(self._lib.dw_conv3x3_f64(self._h, _ffi.ptr_d(x), _ffi.ptr_d(k), _ffi.ptr_d(out)))
         return out
 
+    def stage(self, stage, planes, L=0.0, kernel=None):
+        """One stage of forward() on caller data, on the device (dw_stage_f64): `planes` = the stage's input
+        planes, each (B,H,W); returns the list of its output planes."""
+        n_in, n_out = _ffi.STAGE_IO[stage]
+        if len(planes) != n_in:
+            raise ValueError(f"stage {stage} takes {n_in} planes, got {len(planes)}")
+        x = np.ascontiguousarray(np.stack([self._plane(a, np.float64) for a in planes]))
+        out = np.empty((n_out, self.B, self.H, self.W))
+        k = None if kernel is None else np.ascontiguousarray(kernel, dtype=np.float64).reshape(9)
+        self._check(self._lib.dw_stage_f64(self._h, int(stage), _ffi.ptr_d(x), _ffi.ptr_d(out), float(L),
+                                           _ffi.ptr_d(k) if k is not None else None))
+        return list(out)
+
     def get_obs(self, L_init=0.75):
         obs = np.zeros((self.B, self.N, 7, 3, 3))
         if self.B * self.N:
