@@ -12,9 +12,10 @@ max-over-ranks timing and a final gather of per-world statistics.  `--gpus N` wi
 environment launches the N ranks itself (children only: the parent never touches the GPU).
 
 Default workload: the north-star shape, 1024 worlds of 4096x4096 on ONE GPU (128 GiB of binary16 ping-pong
-state; if the allocation fails the world count is halved until it fits and the line says so).  The C2
-workload (BASELINE configs[1], 1024 x 256^2) is measured in the same invocation and reported under
-"workloads".  Arithmetic modes: the headline is `fast` - float32 arithmetic, the "stated fp32 tolerance" of the
+state; if the allocation fails the world count is halved until it fits and the line says so).  The other
+BASELINE configs - c2 (1024 x 256^2 over the whole ramp), c3 (256 x 1024^2, a greedy agent), c4 (the 1000 x 256^2
+shard with 4 greedy agents and per-step biosphere flags; also at the README's 8x8 grid) and c5 (the 8 x 8192^2
+shard, 16 mixed-policy agents) - are measured in the same invocation, both modes, and reported under "workloads".  Arithmetic modes: the headline is `fast` - float32 arithmetic, the "stated fp32 tolerance" of the
 north star: from identical states every cell within one quantum (1e-3) and >= 99.98 % of the cell values
 identical per step (measured >= 99.994 % on developed states over the whole luminosity ramp,
 profiles/r02_fast_tolerance.json; asserted by tests/test_gpu_parity.py); `exact` - float32 plus a float64
@@ -59,9 +60,13 @@ WORKLOADS = {
     "c2": (1024, 256, 0, "BASELINE configs[1]: 1024 worlds, 256x256, no agent, ramped luminosity"),
     "c3": (256, 1024, 1, "BASELINE configs[2]: 256 worlds, 1024x1024, 1 greedy agent per world"),
     "c5": (8, 8192, 16, "BASELINE configs[4] per-GPU shard: 8 worlds, 8192x8192, 16 mixed-policy agents"),
-    "c4": (1000, 8, 4, "BASELINE configs[3] per-GPU shard at the README's grid: 1000 worlds, 8x8, 4 greedy agents, "
-                       "device-resident episode loop (dw_run_episode)"),
+    "c4": (1000, 256, 4, "BASELINE configs[3] per-GPU shard: 1000 worlds, 256x256, 4 greedy agents, device-resident "
+                         "episode loop with per-step biosphere flags (dw_run_episode, as the lifespan sweep runs it)"),
+    "c4_dim8": (1000, 8, 4, "BASELINE configs[3] per-GPU shard at the README's own grid: 1000 worlds, 8x8, 4 greedy agents, "
+                            "LDS-resident episode kernel (dw_run_episode)"),
 }
+# what the default invocation measures beside the headline workload: (timed steps, warm-up steps, pre-heat seconds)
+EXTRA_WORKLOADS = {"c2": (512, 64, 0.5), "c3": (64, 8, 0.3), "c4": (64, 8, 0.3), "c4_dim8": (256, 32, 0.2), "c5": (32, 8, 0.3)}
 
 
 def parse(argv=None):
@@ -85,7 +90,7 @@ def parse(argv=None):
                     help="self-launched N > 1 runs: kill every rank and exit 124 when the run takes longer")
     ap.add_argument("--rank-log-dir", default="", help="self-launched N > 1 runs: keep the per-rank logs here")
     ap.add_argument("--no-modes", action="store_true", help="skip the extra run in the other arithmetic mode")
-    ap.add_argument("--no-workloads", action="store_true", help="skip the extra C2 measurement")
+    ap.add_argument("--no-workloads", action="store_true", help="skip the extra measurements of c2 ... c5")
     ap.add_argument("--selftest-spawn", action="store_true",
                     help="CPU rehearsal of the N > 1 plumbing (rank launch, rendezvous, barrier, max-over-ranks, "
                          "gather, rank-0 relay) without touching a GPU: prints the JSON skeleton")
@@ -159,21 +164,30 @@ def cpu_baseline(grid: int, budget_s: float = 15.0):
 def load_profile(kind: str, workload: str, precision: str):
     """Newest committed PMC summary for (workload, precision): kind 'traffic' -> profiles/traffic_*.json (HBM bytes
     per fused launch: separate --pmc passes, FETCH_SIZE x2 on gfx950), kind 'valu' -> profiles/*_valu_pmc.json
-    (SQ counters of the fused kernel).  Returns (dict, file name) or (None, None)."""
+    (SQ counters of the fused kernel).  Returns (dict, file name, meta) or (None, None, None); meta = the build id
+    and shape the profile was taken on (absent in the profiles of rounds 1-2)."""
     pat = "traffic_*.json" if kind == "traffic" else "*_valu_pmc.json"
     best = None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", pat))):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", pat)), key=lambda q: (json_round(q), q)):
         try:
             d = json.load(open(path))
         except Exception:
             continue
+        meta = {"library_build_id": d.get("library_build_id"), "worlds_per_gpu": d.get("worlds_per_gpu"), "grid": d.get("grid")}
         if kind == "traffic":
             if d.get("workload") == workload and d.get("precision") == precision and d.get("plane_elem_bytes", 4) == 2:
-                best = (d.get("fused") or d, os.path.basename(path))
+                best = (d.get("fused") or d, os.path.basename(path), meta)
         else:
             if str(d.get("workload", "")).split()[0] == workload and d.get("plane_elem_bytes", 4) == 2 and precision in d:
-                best = (d[precision], os.path.basename(path))
-    return best if best else (None, None)
+                best = (d[precision], os.path.basename(path), meta)
+    return best if best else (None, None, None)
+
+
+def json_round(path):
+    try:
+        return int(json.load(open(path)).get("round", 0))
+    except Exception:
+        return 0
 
 
 def selftest_spawn(args):
@@ -298,8 +312,8 @@ def main():
                     coin = rng.rand(k) > 0.5
                     table[:, :, 12:16] = np.where(coin[:, None, None], -1, rng.randint(9, size=(k, B, 4)))
                     eng.run_episode(Ls, _ffi.POLICY_TABLE, None, table, world_flags=False)
-                elif workload == "c4":
-                    eng.run_episode(Ls, _ffi.POLICY_ARGMAX)
+                elif workload in ("c4", "c4_dim8"):
+                    eng.run_episode(Ls, _ffi.POLICY_ARGMAX)         # with the per-step world flags of the sweep
                 else:
                     eng.run_episode(Ls, _ffi.POLICY_ARGMAX, world_flags=False)
                 nsteps -= k
@@ -373,18 +387,33 @@ def main():
             src = "HIP events over the whole timed region / steps (includes the agent and policy kernels)"
         alg = bpc * m["cells"] * spl
         achieved = alg / (launch_ms * 1e-3) / 1e9
-        tr, tr_file = load_profile("traffic", m["workload"], m["precision"])
-        va, va_file = load_profile("valu", m["workload"], m["precision"])
+        tr, tr_file, tr_meta = load_profile("traffic", m["workload"], m["precision"])
+        va, va_file, va_meta = load_profile("valu", m["workload"], m["precision"])
+        live_id = _ffi.load().dw_build_id().decode()
+
+        def provenance(meta, fname):
+            """Where a committed counter profile came from, and whether it describes THIS library and shape."""
+            same_build = meta.get("library_build_id") == live_id
+            same_shape = meta.get("worlds_per_gpu") == m["B"] and meta.get("grid") == [m["G"], m["G"]]
+            return {"file": f"profiles/{fname}", "library_build_id": meta.get("library_build_id"),
+                    "worlds_per_gpu": meta.get("worlds_per_gpu"), "grid": meta.get("grid"),
+                    "stale": not same_build, "same_shape": same_shape}
         # the committed profile may be of another world count: scale its bytes per cell-update to this run's launch
         traffic = tr["hbm_bytes_per_cell_update"] * m["cells"] * spl if tr and spl == 2 else None
         measured = traffic / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if traffic else None
         valu = None
         if va and spl == 2:
             valu = {"instr_per_cell_eval": va["derived"]["valu_instr_per_cell_eval"],
-                    "busy_frac": va["derived"]["valu_busy_fraction"], "source": f"profiles/{va_file}"}
+                    "busy_frac": va["derived"]["valu_busy_fraction"], "profile": provenance(va_meta, va_file)}
         bound = "valu" if (valu and valu["busy_frac"] >= 0.7 and (measured is None or measured < 0.6)) else "hbm"
         return {"bound": bound, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "measured_frac": measured,
+                # two fractions, named for what they are (ADVICE r2): `frac` = ALGORITHMIC bytes / time / peak - the
+                # task's accounting, a throughput figure in byte units; `hbm_frac_measured` = bytes the memory system
+                # actually moved (PMC) / time / peak - how busy HBM is.  A fused launch moves about half its
+                # algorithmic bytes, so the first is about twice the second; the kernel is VALU-bound (`bound`).
+                "frac": achieved / HBM_PEAK_GBS, "frac_is": "algorithmic bytes / launch time / peak",
+                "traffic": traffic, "measured_frac": measured, "hbm_frac_measured": measured,
+                "traffic_profile": provenance(tr_meta, tr_file) if traffic else None,
                 "traffic_source": f"profiles/{tr_file} (PMC passes of the same command, collected separately)" if traffic else None,
                 "valu": valu, "bytes_per_cell_update": bpc, "plane_elem_bytes": m["plane_elem_bytes"],
                 "steps_per_launch": spl, "cell_updates_per_launch": m["cells"] * spl,
@@ -432,8 +461,10 @@ def main():
         other = "fast" if args.precision == "exact" else "exact"
         out["modes"] = {other: brief(measure(args.workload, other, args.steps, args.warmup, min(args.preheat_s, 1.0), B))}
     if not args.no_workloads and args.workload == "target":
-        # BASELINE configs[1] in the same invocation: the whole luminosity ramp (512 steps after 64 of warm-up)
-        out["workloads"] = {"c2": {p: brief(measure("c2", p, 512, 64, 0.5)) for p in ("exact", "fast")}}
+        # every BASELINE config in the same invocation, both arithmetic modes: c2 over the whole luminosity ramp
+        # (512 steps after 64 of warm-up), the agent workloads c3 / c4 / c5 as short runs of their per-GPU shard
+        out["workloads"] = {w: {p: brief(measure(w, p, k, wu, ph)) for p in ("exact", "fast")}
+                            for w, (k, wu, ph) in EXTRA_WORKLOADS.items()}
     if rank == 0:
         cc = copy_ceiling()
         out["roofline"]["copy_ceiling"] = cc

@@ -96,6 +96,21 @@ struct dw_handle {
     StripGeom sgeom{};
     bool allow_fuse = false;          // wide grids: dw_step_n / dw_run_episode fuse pairs of steps
     bool fused_ring = false;          // W == 1024: the four waves of a workgroup form a ring over the torus row
+    // Exact mode, adaptive strip height: a wave whose repair queue overflows recomputes its whole strip
+    // in float64 (4-6x slower) and stores the launch's sequence number into `ovf` - one word of page-locked host
+    // memory the device writes through - which the host reads (no synchronisation) before the next exact launch:
+    // an overflow seen from a launch issued at the current height halves the height of the following launches
+    // (twice the queue room per cell); after `clean_needed` launches without one it is doubled again, and every
+    // relapse doubles that patience.
+    unsigned int* ovf_host = nullptr;
+    unsigned int* ovf_dev = nullptr;
+    unsigned int launch_seq = 0;      // sequence number of the last exact wave-strip launch
+    unsigned int sr_since_seq = 0;    // first launch issued at the current strip height
+    int sr_base = 0, sr_cur = 0;      // the height select_kernel chose / the height in use
+    int clean_launches = 0, clean_needed = 32;
+    bool adapt = false;
+    bool sym_albedo = false;          // a_dark - a_bare == -(a_light - a_bare) exactly: the exact wave-strip kernels use
+                                      // the two-term coefficient chain (growth_t<.., SYM>)
     FusedGeom fgeom{};
     int* done_at = nullptr;           // [B]
     int* agents_done_at = nullptr;    // [B][N]
@@ -249,6 +264,15 @@ static PhysF64 make_f64(const dw_params& p, double L) {
     return P;
 }
 
+#ifndef DW_TIE_BOUND
+#define DW_TIE_BOUND 3
+#endif
+// kbeta = 1 / sqrt(g To^2) in float64 (g = 0: a denominator so large that w^2 vanishes)
+static double cbeta_host(const dw_params& p) {
+    const double cbeta = p.g * p.temp_optimal * p.temp_optimal;
+    return cbeta > 1e-30 ? 1.0 / std::sqrt(cbeta) : 0x1p60;
+}
+
 static void split_hi_lo(double v, double scale, float* hi, float* lo) {
     const double h = std::nearbyint(v * scale) / scale;
     *hi = (float)h;
@@ -270,7 +294,7 @@ static PhysF32 derive_f32(const dw_params& p, double L, int hb_cap = 40) {
     const double c0d = e0 + p.q2 * (p.albedo_bare * p.p - p.albedo_dark) / To4;
     // hi parts are multiples of 2^-hb with hb chosen so that every partial sum of the hi chain
     // (|.| <= maxsum) stays below 2^(24-hb): exactly representable in float32 for integer inputs.
-    const double kmax = 1000.0 * p.p;
+    const double kmax = 1000.0;                                  // covers are clipped to [0, 1] whatever p is (ref :449)
     const double maxsum = std::fabs(a1) * 8 * kmax + std::fabs(a2) * 8 * kmax + std::fabs(a3) * kmax +
                           std::fabs(a4) * kmax + std::fmax(std::fabs(c0l), std::fabs(c0d));
     int hb = 23 - (int)std::ceil(std::log2(std::fmax(maxsum, 1e-30)));
@@ -309,21 +333,70 @@ static PhysF32 derive_f32(const dw_params& p, double L, int hb_cap = 40) {
     // absolute error of e: only the lo chain rounds (hi chain exact); lo coefficients <= 2^-(hb+1)
     const double lo_mag = std::ldexp(1.0, -(hb + 1)) * 18.0 * kmax + std::ldexp(1.0, -(hb + 1));
     const double de_abs = 6.0 * u * lo_mag + 1e-9;
-    // largest |(T-To)/To| over admissible states (signs of the coefficients respected)
-    const double pos = std::fmax(std::fmax(a1, a2), 0.0) * 8 * kmax + std::fmax(std::fmax(a3, a4), 0.0) * kmax;
-    const double neg = std::fmin(std::fmin(a1, a2), 0.0) * 8 * kmax + std::fmin(std::fmin(a3, a4), 0.0) * kmax;
+    // admissible interval of e over all states with covers in [0, kmax] (signs of the coefficients respected)
+    // (light and dark cover are clipped separately: both may be full in the same cell)
+    const double pos = (std::fmax(a1, 0.0) + std::fmax(a2, 0.0)) * 8 * kmax + (std::fmax(a3, 0.0) + std::fmax(a4, 0.0)) * kmax;
+    const double neg = (std::fmin(a1, 0.0) + std::fmin(a2, 0.0)) * 8 * kmax + (std::fmin(a3, 0.0) + std::fmin(a4, 0.0)) * kmax;
     const double emax = std::fmax(c0l, c0d) + pos, emin = std::fmin(c0l, c0d) + neg;
+#if DW_TIE_BOUND == 2
+    // round-2 constants (kept for A/B runs: -DDW_TIE_BOUND=2)
     const double dabs = std::fmax(std::fabs(std::pow(std::fmax(1.0 + emax, 1e-6), 0.25) - 1.0),
                                   std::fabs(std::pow(std::fmax(1.0 + emin, 1e-6), 0.25) - 1.0));
     const double cb = p.g * p.temp_optimal * p.temp_optimal;
-    const double safety = 1.25;   // on top of the worst-case analysis; the audit (dw_audit_tie_bound) sees <= 0.25 of eps
+    const double safety = 1.25;
     const double A0 = safety * (0.25 * kmax * std::fabs(p.dt) * cb * dabs * de_abs + 4.0 * u * kmax * 0.25 + 2e-5);
+    const double eA = safety * 9.0 * u, eK0d = safety * 5.0 * u, eK1d = safety * 28.0 * u;
+#else
+    // Round-3 derivation (every step numbered there).  With v = 1 + e, s = sqrt(v), y = sqrt(s),
+    // D = kbeta (y+1)(s+1), w = e/D, om = w^2, the hardware's sqrt / rcp at 1 ulp (relative 2u) and every other
+    // operation correctly rounded (relative u):
+    //   rel(v)  <= u (1 + re) + de/vmin =: ev                 re = max |e| / (1 + e)
+    //   rel(D)  <= 3u + (ev/2 + 2u) sg + (ev/4 + 3u) et       sg = max s/(s+1), et = max y/(y+1)
+    //   rel(w)  <= 4u + rel(D) + de/|e| = ew + de/|e|
+    //   |beta^ - beta| <= 2 ew om + u (1 + om) + 2 de max(|e| / D^2)
+    //   |kb^ - kb| <= pu + 6u Dt + u |kb|       (kb = p - Dt, Dt = ck S the summed densities: S carries 5u, ck u; pu = u|p|
+    //                                             unless p is a float) <= pu + 6u|p| + 7u|kb| [kb < 0]
+    //   |f^ - f| <= (pu + 6u|p|)(1 + om) + 7u (|f| + |gamma|) + kbmax (2 ew om + u (1 + om) + Ae) + u |gamma| + u |f|
+    //               (|beta^| <= 1 + om; |kb beta| = |f + gamma|)
+    //   |gq^ - gq| <= |K| |f^ - f| + 5u |gq|        (K carries 4u, the product u)
+    // kbmax = max |kb| over states with covers in [0, 1]: the two densities sum to [0, 2].
+    const double vmin = 1.0 + emin, vmax = 1.0 + emax;
+    const bool admissible = vmin > 0.02;                          // otherwise: flag every cell (float64 everywhere)
+    const double vlo = std::fmax(vmin, 0.02);
+    const double smax = std::sqrt(std::fmax(vmax, vlo));
+    const double ymax = std::sqrt(smax);
+    const double sg = smax / (smax + 1.0), et = ymax / (ymax + 1.0);
+    const double re = std::fmax(std::fabs(emin) / vlo, std::fabs(emax) / std::fmax(vmax, vlo));
+    const double ev = u * (1.0 + re) + de_abs / vlo;
+    const double eD = 3.0 * u + (0.5 * ev + 2.0 * u) * sg + (0.25 * ev + 3.0 * u) * et;
+    const double ew = 4.0 * u + eD;
+    const double kbe = cbeta_host(p);                            // kbeta in float64
+    auto e_over_D2 = [&](double e) {
+        const double v = std::fmax(1.0 + e, vlo), sv = std::sqrt(v), yv = std::sqrt(sv);
+        const double D = kbe * (yv + 1.0) * (sv + 1.0);
+        return std::fabs(e) / (D * D);
+    };
+    const double Ae = 2.0 * de_abs * std::fmax(e_over_D2(emin), e_over_D2(emax));
+    const double kbmax = std::fmax(std::fabs(p.p), std::fabs(p.p - 2.0));
+    const double safety = 1.0 + 0x1p-7;                           // the second-order terms dropped above (~u relative)
+    const double pu = (double)(float)p.p == p.p ? 0.0 : std::fabs(p.p);
+    double A0 = safety * (kmax * std::fabs(p.dt) * kbmax * Ae + 2e-6);   // 2e-6: the float32 arithmetic of the threshold
+    if (!admissible) A0 = 1.0;                                    // tie_lo < 0: every cell goes to float64
+    const double eA = safety * 13.0 * u;
+    const double eK0d = safety * (6.0 * std::fabs(p.p) + pu + kbmax + 8.0 * std::fabs(p.gamma)) * u;
+    const double eK1d = safety * ((6.0 * std::fabs(p.p) + pu) * u + kbmax * (u + 2.0 * ew));
+#endif
+    auto up = [](double v) { float f = (float)v; return (double)f < v ? std::nextafterf(f, INFINITY) : f; };   // never round a bound DOWN
     P.tie_lo = (float)(0.5 - A0);
-    P.eA = (float)(safety * 9.0 * u);
-    P.eK0 = (float)(safety * 5.0 * u);
-    P.eK1 = (float)(safety * 28.0 * u);
-    P.eK0s = p.dt < 0.0 ? P.eK0 : -P.eK0;
-    P.eK1s = p.dt < 0.0 ? P.eK1 : -P.eK1;
+    if ((double)P.tie_lo > 0.5 - A0) P.tie_lo = std::nextafterf(P.tie_lo, -INFINITY);
+    P.eA = up(eA);
+    const float eK0 = up(eK0d), eK1 = up(eK1d);
+    P.eK0s = p.dt < 0.0 ? eK0 : -eK0;
+    P.eK1s = p.dt < 0.0 ? eK1 : -eK1;
+    P.neK1s = -P.eK1s;                                           // the bracket in beta: (eK0s + eK1s) - eK1s*beta
+    P.eK01s = (float)((double)P.eK0s + (double)P.eK1s);
+    if (std::fabs((double)P.eK01s) < std::fabs((double)P.eK0s + (double)P.eK1s))     // never round the bound DOWN
+        P.eK01s = std::nextafterf(P.eK01s, P.eK01s < 0.f ? -1.f : 1.f);
     return P;
 }
 
@@ -343,12 +416,53 @@ static void derive_f32_pair(const dw_params& p, double L1, double L2, PhysF32* P
 // ------------------------------------------------------------------------------------------------
 // kernel selection
 // ------------------------------------------------------------------------------------------------
+// strip counts / grid sizes of the wave-strip kernels for strips of `sr` rows (select_kernel; adapt_strip_rows)
+static void set_strip_rows(dw_handle* h, int sr) {
+    const dw_params& p = h->prm;
+    StripGeom& g = h->sgeom;
+    FusedGeom& f = h->fgeom;
+    const bool packed = g.wpr > 1 || p.width < 256;
+    const long groups = packed ? (p.batch + g.wpr - 1) / g.wpr : p.batch;
+    g.SR = f.SR = p.height < sr ? p.height : sr;
+    g.nrs = f.nrs = (p.height + g.SR - 1) / g.SR;
+    g.nstrips = (int)(groups * g.nrs * g.ncs);
+    g.nwg = (g.nstrips + 3) / 4;
+    g.chunk = (g.nwg + 7) / 8;
+    f.nstrips = (int)(groups * f.nrs * f.ncs);
+    f.nwg = h->fused_ring ? f.nstrips : (f.nstrips + 3) / 4;
+    f.chunk = (f.nwg + 7) / 8;
+    h->sr_cur = g.SR;
+}
+
+// Called before every exact wave-strip launch: react to the overflow word (see dw_handle) and hand out the
+// launch's sequence number.
+static unsigned int adapt_strip_rows(dw_handle* h) {
+    const unsigned int seq = ++h->launch_seq;
+    if (!h->adapt || !h->ovf_host) return seq;
+    const unsigned int seen = *reinterpret_cast<volatile unsigned int*>(h->ovf_host);
+    const bool overflowed = seen != 0 && (int)(seen - h->sr_since_seq) >= 0;     // by a launch at the current height
+    if (overflowed) {
+        h->clean_launches = 0;
+        if (h->sr_cur > 8) {
+            set_strip_rows(h, h->sr_cur / 2);
+            h->sr_since_seq = seq;
+            if (h->clean_needed < 4096) h->clean_needed *= 2;
+        }
+    } else if (h->sr_cur < h->sr_base && ++h->clean_launches >= h->clean_needed) {
+        set_strip_rows(h, h->sr_cur * 2 < h->sr_base ? h->sr_cur * 2 : h->sr_base);
+        h->sr_since_seq = seq;
+        h->clean_launches = 0;
+    }
+    return seq;
+}
+
 static void select_kernel(dw_handle* h) {
     const dw_params& p = h->prm;
     h->tcq = 0;
     h->rpt = 0;
     h->use_stream = false;
     h->allow_fuse = false;
+    h->sym_albedo = (p.albedo_dark - p.albedo_bare) == -(p.albedo_light - p.albedo_bare) && !std::getenv("DW_NO_SYM");
     if (p.precision == DW_PRECISION_F64) return;
     if (p.width % 4 != 0) return;
     const int Wq = p.width / 4;
@@ -383,10 +497,10 @@ static void select_kernel(dw_handle* h) {
             if (const char* e = std::getenv("DW_STRIP_ROWS")) { const int v = std::atoi(e); if (v >= 1) sr = v; }
             g.SR = p.height < sr ? p.height : sr;
         }
-        g.nrs = (p.height + g.SR - 1) / g.SR;
-        g.nstrips = (packable ? (p.batch + g.wpr - 1) / g.wpr : p.batch) * g.nrs * g.ncs;
-        g.nwg = (g.nstrips + 3) / 4;
-        g.chunk = (g.nwg + 7) / 8;
+        h->sr_base = h->sr_cur = g.SR;
+        h->sr_since_seq = h->launch_seq + 1;
+        h->clean_launches = 0;
+        h->adapt = !std::getenv("DW_NO_ADAPT") && !std::getenv("DW_STRIP_ROWS");
         g.qcap = kWaveQueueCap;
         int mcap = kMismatchCap;
         if (const char* e = std::getenv("DW_TEST_QUEUE_CAP")) {  // tests: force the overflow fallbacks
@@ -407,12 +521,9 @@ static void select_kernel(dw_handle* h) {
         h->fused_ring = p.width == 1024 && !std::getenv("DW_NO_RING");
         f.cols_per_strip = p.width <= 256 ? 256 : (h->fused_ring ? 1024 : 248);
         f.ncs = packable ? 1 : (p.width + f.cols_per_strip - 1) / f.cols_per_strip;
-        f.nrs = (p.height + f.SR - 1) / f.SR;
-        f.nstrips = (packable ? (p.batch + f.wpr - 1) / f.wpr : p.batch) * f.nrs * f.ncs;
-        f.nwg = h->fused_ring ? f.nstrips : (f.nstrips + 3) / 4;
-        f.chunk = (f.nwg + 7) / 8;
         f.qcap = g.qcap;
         f.mcap = mcap;
+        set_strip_rows(h, g.SR);
         return;
     }
     if (Wq >= 64) {
@@ -519,6 +630,7 @@ static int launch_forward(dw_handle* h, double L) {
         HIPCHK(hipGetLastError());
     } else if (h->use_stream) {
         const bool ex = prec == DW_PRECISION_EXACT;
+        const unsigned int ovf_seq = ex ? adapt_strip_rows(h) : 0u;      // may change the strip height: before `g`
         const StripGeom& g = h->sgeom;
         const dim3 grid((unsigned)g.chunk * 8u);
         const int halo = p.width < 256 ? 3 : (p.width == 256 ? 0 : (p.width % 256 == 0 ? 1 : 2));
@@ -527,11 +639,14 @@ static int launch_forward(dw_handle* h, double L) {
                        h->D16[out], g, P, P64, stats, fixups, zero_me, zero_n)
         if (ex) {
             const StreamExactArgs A{h->L16[in], h->D16[in], h->L16[out], h->D16[out], g, P, stats, fixups, zero_me,
-                                    zero_n, P64};
-            if (halo == 0) hipLaunchKernelGGL((step_stream_exact<0>), grid, dim3(256), 0, h->stream, A);
-            else if (halo == 1) hipLaunchKernelGGL((step_stream_exact<1>), grid, dim3(256), 0, h->stream, A);
-            else if (halo == 2) hipLaunchKernelGGL((step_stream_exact<2>), grid, dim3(256), 0, h->stream, A);
-            else hipLaunchKernelGGL((step_stream_exact<3>), grid, dim3(256), 0, h->stream, A);
+                                    zero_n, P64, h->ovf_dev, ovf_seq};
+#define DW_SX(HL)                                                                                     \
+    do {                                                                                              \
+        if (h->sym_albedo) hipLaunchKernelGGL((step_stream_exact<HL, true>), grid, dim3(256), 0, h->stream, A); \
+        else hipLaunchKernelGGL((step_stream_exact<HL, false>), grid, dim3(256), 0, h->stream, A);     \
+    } while (0)
+            if (halo == 0) DW_SX(0); else if (halo == 1) DW_SX(1); else if (halo == 2) DW_SX(2); else DW_SX(3);
+#undef DW_SX
         } else {
             if (halo == 0) DW_STREAM(step_stream_fast, 0);
             else if (halo == 1) DW_STREAM(step_stream_fast, 1);
@@ -577,13 +692,18 @@ static int launch_forward_fused2(dw_handle* h, double L1, double L2, unsigned in
     else { P1 = derive_f32(p, L1); P2 = derive_f32(p, L2); }
     unsigned long long* zero_me = reinterpret_cast<unsigned long long*>(h->stats2[h->sp]);
     const int zero_n = (int)(h->stats_bytes / sizeof(unsigned long long));
+    const unsigned int ovf_seq = p.precision == DW_PRECISION_EXACT ? adapt_strip_rows(h) : 0u;   // before `g`
     const FusedGeom& g = h->fgeom;
     const dim3 grid((unsigned)g.chunk * 8u);
     const bool rot = p.width == 256, pack = p.width < 256, ring = h->fused_ring;
     if (p.precision == DW_PRECISION_EXACT) {
         const FusedExactArgs A{h->L16[in], h->D16[in], h->L16[out], h->D16[out], g, P1, lum_part(P2), zero_me, zero_n,
-                               pstats, thr_hi, make_f64(p, L1), L1, L2};
-#define DW_FX(R, P, S) hipLaunchKernelGGL((step_stream_fused2_exact<R, P, S>), grid, dim3(256), 0, h->stream, A)
+                               pstats, thr_hi, make_f64(p, L1), L1, L2, h->ovf_dev, ovf_seq};
+#define DW_FX(R, P, S)                                                                                            \
+    do {                                                                                                          \
+        if (h->sym_albedo) hipLaunchKernelGGL((step_stream_fused2_exact<R, P, S, true>), grid, dim3(256), 0, h->stream, A); \
+        else hipLaunchKernelGGL((step_stream_fused2_exact<R, P, S, false>), grid, dim3(256), 0, h->stream, A);     \
+    } while (0)
         if (pstats) {
             if (pack) DW_FX(kFusedRot, true, true); else if (rot) DW_FX(kFusedRot, false, true);
             else if (ring) DW_FX(kFusedRing, false, true); else DW_FX(kFusedOvl, false, true);
@@ -752,6 +872,9 @@ int dw_create(const dw_params* p, dw_handle** out) {
     TRY(hipMemsetAsync(h->agents_done_at, 0, sizeof(int) * bn, h->stream));
     TRY(hipMemsetAsync(h->n_alive, 0, sizeof(int), h->stream));
     TRY(hipMalloc(&h->side_stats, sizeof(StatsDev) * (p->batch + 1)));
+    TRY(hipHostMalloc(reinterpret_cast<void**>(&h->ovf_host), 64, hipHostMallocMapped));
+    *h->ovf_host = 0u;
+    TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->ovf_dev), h->ovf_host, 0));
     TRY(hipEventCreate(&h->ev0));
     TRY(hipEventCreate(&h->ev1));
     TRY(hipEventCreate(&h->evf0));
@@ -772,6 +895,7 @@ int dw_destroy(dw_handle* h) {
     (void)hipFree(h->idx); (void)hipFree(h->st); (void)hipFree(h->action); (void)hipFree(h->action_tmp);
     (void)hipFree(h->reward_d); (void)hipFree(h->done_d);
     if (h->pinned) (void)hipHostFree(h->pinned);
+    if (h->ovf_host) (void)hipHostFree(h->ovf_host);
     (void)hipFree(h->snapL); (void)hipFree(h->snapD); (void)hipFree(h->snap_idx); (void)hipFree(h->snap_st);
     (void)hipFree(h->snapPL); (void)hipFree(h->snapPD);
     (void)hipFree(h->snap_stats);

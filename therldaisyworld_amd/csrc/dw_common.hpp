@@ -106,10 +106,12 @@ __device__ __forceinline__ Row4 load_row(const float* __restrict__ lds_row_group
 
 // The map on the four cells of one row group: (up, mid, down) rows of both planes -> new values (and,
 // in the exact mode, the near-tie flags).  Two cells per packed float32 lane pair (dw_physics.hpp).
-template <bool EXACT>
+// `tie`: per-lane bools (bool*), or - the wave-strip kernels - the wave's lane masks (unsigned long long*), which
+// stay on the scalar unit from the compare to the queue push.
+template <bool EXACT, bool SYM = false, typename F = bool>
 __device__ __forceinline__ void cells4(const PhysF32& P, const Row4& upL, const Row4& miL, const Row4& dnL,
                                        const Row4& upD, const Row4& miD, const Row4& dnD, float* ol, float* od,
-                                       bool* tie) {
+                                       F* tie) {
 #pragma clang fp contract(off)
 #ifdef DW_SCALAR_CELLS
     using T = float;
@@ -125,14 +127,19 @@ __device__ __forceinline__ void cells4(const PhysF32& P, const Row4& upL, const 
         const T Cl = pr(upL.h2) + pr(dnL.h2);
         const T Ed = pr(miD.h2) + (pr(upD.x) + pr(dnD.x));
         const T Cd = pr(upD.h2) + pr(dnD.h2);
-        const GrowthT<T> g = growth_t<EXACT || kFastSplit, T>(P, li, di, El, Cl, Ed, Cd);
+        const GrowthT<T> g = growth_t<EXACT || kFastSplit, T, EXACT && SYM>(P, li, di, El, Cl, Ed, Cd);
         T vl, vd;
         if (EXACT) {
-            bool tl[N], td[N];
-            vl = finish_exact_t<T>(P, li, g.gql, g.dKl, g.oml, tl);
-            vd = finish_exact_t<T>(P, di, g.gqd, g.dKd, g.omd, td);
+            F tl[N], td[N];
+            if constexpr (DW_TIE_FROM_BETA || sizeof(F) == 8) {
+                vl = finish_exact_beta_t<T, F>(P, li, g.gql, g.dKl, g.bl, tl);
+                vd = finish_exact_beta_t<T, F>(P, di, g.gqd, g.dKd, g.bd, td);
+            } else {
+                vl = finish_exact_t<T>(P, li, g.gql, g.dKl, g.oml, tl);
+                vd = finish_exact_t<T>(P, di, g.gqd, g.dKd, g.omd, td);
+            }
 #pragma unroll
-            for (int e = 0; e < N; ++e) tie[i + e] = tl[e] || td[e];
+            for (int e = 0; e < N; ++e) tie[i + e] = tl[e] | td[e];
         } else {
             vl = finish_fast_t<T>(li, g.dKl, g.fl);
             vd = finish_fast_t<T>(di, g.dKd, g.fd);

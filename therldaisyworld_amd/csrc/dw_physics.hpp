@@ -183,7 +183,10 @@ struct PhysF32 {
     //   |frac(gq)| > tie_lo - eA*|gq| - |dt*K|*(eK0 + eK1*om)   =>  re-evaluate in float64
     DW_PAIR(eK1s, eK0s, eKs);    // -sign(dt) * eK1, eK0: dK * (eK0s + eK1s*om) = -|dK| * (eK0 + eK1*om) (density >= 0)
     DW_PAIR(ngamma, tie_lo, gt); // -gamma; the tie threshold's constant part
-    float eA, eK0, eK1;          // eA is used un-packed (|gq| source modifier); eK0 / eK1: host, audit
+    // the same bracket written in beta = 1 - om (the hot kernels have beta, not om):
+    //   eK0s + eK1s*om = (eK0s + eK1s) + (-eK1s)*beta
+    DW_PAIR(neK1s, eK01s, eKb);
+    float eA;                    // used un-packed (|gq| source modifier); eK0 = |eK0s|, eK1 = |eK1s| (host, audit)
     int hi_bits;                 // the hi parts are multiples of 2^-hi_bits (host bookkeeping)
 };
 static_assert(sizeof(PhysF32) == 32 * sizeof(float), "PhysF32 layout");
@@ -220,6 +223,11 @@ template <> struct Lanes<float> {
     static __device__ __forceinline__ float clip(float v) { return fminf(fmaxf(v, 0.0f), 1000.0f); }
     static __device__ __forceinline__ float get(float v, int) { return v; }
     static __device__ __forceinline__ void gt(float a, float b, bool* out) { out[0] = a > b; }
+    // the same comparison as the wave's 64-bit lane mask (v_cmp writes exactly that into a scalar pair): the hot
+    // kernels combine, test and count tie flags on the scalar unit, with no per-lane booleans in between
+    static __device__ __forceinline__ void gtm(float a, float b, unsigned long long* out) {
+        out[0] = __builtin_amdgcn_fcmpf(a, b, 2 /* FCMP_OGT */);
+    }
     static __device__ __forceinline__ float load(const float* a, int i) { return a[i]; }
     static __device__ __forceinline__ float fma_abs(float a, float b, float c) { return __builtin_fmaf(a, __builtin_fabsf(b), c); }
     static __device__ __forceinline__ float lo(dw_f32x2 pair) { return pair.x; }   // the two constants of a pair
@@ -238,6 +246,10 @@ template <> struct Lanes<dw_f32x2> {
     }
     static __device__ __forceinline__ float get(T v, int i) { return i == 0 ? v.x : v.y; }
     static __device__ __forceinline__ void gt(T a, T b, bool* out) { out[0] = a.x > b.x; out[1] = a.y > b.y; }
+    static __device__ __forceinline__ void gtm(T a, T b, unsigned long long* out) {
+        out[0] = __builtin_amdgcn_fcmpf(a.x, b.x, 2 /* FCMP_OGT */);
+        out[1] = __builtin_amdgcn_fcmpf(a.y, b.y, 2);
+    }
     static __device__ __forceinline__ T load(const float* a, int i) { return T{a[i], a[i + 1]}; }
     // a*|b| + c per lane with the scalar VOP3 fma: its |.| source modifier is free, packed ops have none
     static __device__ __forceinline__ T fma_abs(float a, T b, float c) {
@@ -253,7 +265,8 @@ struct GrowthT {
     T gql, gqd;                  // per-mille growth dt*K*(kb*beta - gamma) for light, dark
     T fl, fd;                    // the factor kb*beta - gamma alone (gq = dK * f)
     T dKl, dKd;                  // dt * density (per-mille), used by the tie bound
-    T oml, omd;                  // 1 - beta_l, 1 - beta_d (>= 0), used by the tie bound
+    T oml, omd;                  // 1 - beta_l, 1 - beta_d (>= 0), used by the tie bound (audit; kernels that have no beta)
+    T bl, bd;                    // beta_l, beta_d: the hot kernels' tie bound reads these instead of om
 };
 using GrowthF32 = GrowthT<float>;
 
@@ -268,14 +281,28 @@ constexpr bool kFastSplit = DW_FAST_SPLIT != 0;
 // El/Cl: sums of the 4 edge / 4 corner neighbours of light; Ed/Cd of dark; li/di the centre.
 // SPLIT = true: hi/lo coefficient chains (exact mode: its tie bound relies on the exact hi chain).
 // SPLIT = false: one float32 coefficient each (float32-only mode: 6 instructions fewer per cell).
-template <bool SPLIT, typename T>
+// SYM (with SPLIT): albedos symmetric about the bare ground's, a_dark - a_bare == -(a_light - a_bare) exactly (the
+// reference's defaults 0.25 / 0.5 / 0.75).  Then a2 = -a1 and a4 = -a3 hold exactly, also for the hi and lo parts,
+// and e_x = c0x + a1*(Sl8 - Sd8) + a3*(li - di): X = Sl8 - Sd8 and Y = li - di are exact integers (|X| <= 8000 <=
+// the 8*kmax the hi grid was sized for), the hi chain a1h*X + a3h*Y is as exact as the four-term one - it is the
+// same number - and the lo chain has two roundings instead of four: 6 packed instructions per cell pair instead of
+// 8 (the host selects the variant: dw_api.hip, `sym_albedo`).
+template <bool SPLIT, typename T, bool SYM = false>
 __device__ __forceinline__ GrowthT<T> growth_t(const PhysF32& P, T li, T di, T El, T Cl, T Ed, T Cd) {
 #pragma clang fp contract(off)
     using V = Lanes<T>;
     const T one = T(1.0f);
     const T Sl8 = El + Cl, Sd8 = Ed + Cd;
     T el, ed;
-    if (SPLIT) {
+    if (SPLIT && SYM) {
+        const T X = Sl8 - Sd8, Y = li - di;                  // exact
+        T hi = V::lo(P.a12h) * X;                            // exact (see above)
+        hi = V::fma(V::lo(P.a34h), Y, hi);
+        T lo = V::fma(V::lo(P.a12l), X, V::hi(P.c0l));
+        lo = V::fma(V::lo(P.a34l), Y, lo);
+        el = (hi + V::lo(P.c0l)) + lo;
+        ed = (hi + V::lo(P.c0d)) + (lo + V::hi(P.c0d));
+    } else if (SPLIT) {
         T hi = V::lo(P.a12h) * Sl8;                         // exact for integer inputs (see above)
         hi = V::fma(V::hi(P.a12h), Sd8, hi);
         hi = V::fma(V::lo(P.a34h), li, hi);
@@ -312,8 +339,10 @@ __device__ __forceinline__ GrowthT<T> growth_t(const PhysF32& P, T li, T di, T E
     o.dKl = V::fma(V::lo(P.dw2kb), Cl, V::fma(V::hi(P.dw01), El, V::lo(P.dw01) * li));
     o.dKd = V::fma(V::lo(P.dw2kb), Cd, V::fma(V::hi(P.dw01), Ed, V::lo(P.dw01) * di));
     const T kb = V::fma(-(o.dKl + o.dKd), V::hi(P.pck), V::lo(P.pck));
-    o.oml = wl * wl;                                        // only the exact mode's tie bound reads these
+    o.oml = wl * wl;                                        // only the audit / the cold exact kernels read these
     o.omd = wd * wd;
+    o.bl = bl;
+    o.bd = bd;
     o.fl = V::fma(kb, bl, V::lo(P.gt));
     o.fd = V::fma(kb, bd, V::lo(P.gt));
     o.gql = o.dKl * o.fl;                                   // the exact finaliser and the audit; the float32-only
@@ -321,10 +350,10 @@ __device__ __forceinline__ GrowthT<T> growth_t(const PhysF32& P, T li, T di, T E
     return o;
 }
 
-template <bool SPLIT = true>
+template <bool SPLIT = true, bool SYM = false>
 __device__ __forceinline__ GrowthF32 growth_f32(const PhysF32& P, float li, float di, float El, float Cl,
                                                 float Ed, float Cd) {
-    return growth_t<SPLIT, float>(P, li, di, El, Cl, Ed, Cd);
+    return growth_t<SPLIT, float, SYM>(P, li, di, El, Cl, Ed, Cd);
 }
 
 // FAST finaliser: k' = rint(clip(k + dK*f, 0, 1000)), the sum in one fused multiply-add (one rounding instead of
@@ -352,6 +381,23 @@ __device__ __forceinline__ T finish_exact_t(const PhysF32& P, T k, T gq, T dK, T
 __device__ __forceinline__ float finish_exact(const PhysF32& P, float k, float gq, float dK, float om,
                                               bool& tie) {
     return finish_exact_t<float>(P, k, gq, dK, om, &tie);
+}
+// The same with the bracket of the threshold written in beta (one packed multiply per cell pair and species fewer:
+// om = w*w is not formed).  1 - beta differs from fl(w*w) by at most u*max(1, om), i.e. the threshold moves by
+// |dK|*eK1*u*(1 + om) <= 1e-9 quanta: inside the rounding floor of tie_lo.
+#ifndef DW_TIE_FROM_BETA
+#define DW_TIE_FROM_BETA 1
+#endif
+template <typename T, typename F>
+__device__ __forceinline__ T finish_exact_beta_t(const PhysF32& P, T k, T gq, T dK, T beta, F* tie) {
+#pragma clang fp contract(off)
+    using V = Lanes<T>;
+    const T r = V::rint(gq);
+    const T frac = V::abs(gq - r);                          // exact (Sterbenz)
+    const T thr = V::fma(dK, V::fma(V::lo(P.eKb), beta, V::hi(P.eKb)), V::fma_abs(-P.eA, gq, P.tie_lo));
+    if constexpr (sizeof(F) == 8) V::gtm(frac, thr, tie);   // F = unsigned long long: lane masks
+    else V::gt(frac, thr, tie);
+    return V::clip(k + r);
 }
 
 // Philox4x32-10 (Salmon et al., SC'11) — counter-based RNG for the synthetic initial states.

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void tie_audit(const plane_t* __restrict__ L, 
     unsigned long long flagged = 0;
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-        const float thr = fmaf(-fabsf(dK[k]), fmaf(P.eK1, om[k], P.eK0), fmaf(-P.eA, fabsf(g32[k]), P.tie_lo));
+        const float thr = fmaf(-fabsf(dK[k]), fmaf(fabsf(P.eK1s), om[k], fabsf(P.eK0s)), fmaf(-P.eA, fabsf(g32[k]), P.tie_lo));
         const double eps = 0.5 - (double)thr;
         const double err = fabs((double)g32[k] - g64[k]);
         max_err = fmax(max_err, err);

@@ -114,13 +114,15 @@ constexpr int kMismatchCap = 64;            // float32 step-1 mismatches per wav
 //                       value above `thr_hi` that cannot be an artefact of float32 or be undone by the few
 //                       cells patched afterwards - a sound lower bound, see agents_lookahead_patch.
 enum { kFusedOvl = 0, kFusedRot = 1, kFusedRing = 2 };
-template <int MODE, bool EXACT, bool PACK = false, bool STATS = false, typename TI = plane_t, typename TO = plane_t>
+template <int MODE, bool EXACT, bool PACK = false, bool STATS = false, bool SYM = false, typename TI = plane_t,
+          typename TO = plane_t>
 __device__ __forceinline__ void fused2_body(const TI* __restrict__ inL, const TI* __restrict__ inD,
                                             TO* __restrict__ outL, TO* __restrict__ outD, const FusedGeom& G,
-                                            const PhysF32& P1, const PhysF32& P2, const PhysF64& P64,
+                                            const PhysF32& P1_, const PhysF32& P2_, const PhysF64& P64,
                                             const double& La, const double& Lb,
                                             unsigned long long* __restrict__ zero_me, int zero_n,
-                                            unsigned int* __restrict__ pstats = nullptr, float thr_hi = 0.f) {
+                                            unsigned int* __restrict__ pstats = nullptr, float thr_hi = 0.f,
+                                            unsigned int* const* ovf = nullptr, const unsigned int* ovf_seq = nullptr) {
     // LAG: step 2 runs one row further behind step 1, on results of earlier iterations only (see below).
     // Measured: exact kernels -5...-11 %, packed float32 -6 %, W = 256 float32 -4 %,
     // overlapped strips -1.5 %.  (-DDW_FUSED_LAG=0 builds the dependent order for comparison.)
@@ -174,6 +176,18 @@ __device__ __forceinline__ void fused2_body(const TI* __restrict__ inL, const TI
         need1[1] = writes;
         need1[2] = writes;
         need1[3] = writes || wr;
+    }
+    // tie flags: lane masks on the scalar unit, except in the STATS and the packed variants (per-lane bools: they are
+    // at their register budget with those and spill inside the row loop otherwise, see dw_step_stream.hpp)
+    constexpr bool LANE_BOOLS = STATS || PACK;
+    using TieT = std::conditional_t<LANE_BOOLS, bool, unsigned long long>;
+    TieT need1m[4], writes_m;
+    if constexpr (LANE_BOOLS) {
+        for (int i = 0; i < 4; ++i) need1m[i] = need1[i];
+        writes_m = writes;
+    } else {
+        for (int i = 0; i < 4; ++i) need1m[i] = lane_mask(need1[i]);
+        writes_m = lane_mask(writes);
     }
     const TI* pL = inL + woff;
     const TI* pD = inD + woff;
@@ -232,29 +246,43 @@ __device__ __forceinline__ void fused2_body(const TI* __restrict__ inL, const TI
         ring_par ^= 1;
     };
     unsigned int nq = 0;                                        // queued entries of this wave (uniform)
+    // PIN (exact kernels that have the registers): a packed instruction reads at most ONE scalar pair, so the
+    // addend constants of the fmas whose multiplier is a scalar pair too - the lo chain's seed c0l, p of the bare
+    // fraction, the tie bracket's constant, tie_lo beside eA - were copied into VGPRs again and again (the compiler
+    // rematerialises them per row map: ~1.1 v_mov per cell-evaluation).  Held in VGPRs for the whole strip instead.
+#ifndef DW_PIN_CONSTS
+#define DW_PIN_CONSTS 14
+#endif
+    PhysF32 P1 = P1_, P2 = P2_;
+    if constexpr (EXACT && DW_PIN_CONSTS != 0 && !STATS && !PACK) {   // bit mask: 1 c0l (both steps), 2 pck, 4 eKb, 8 gt
+        if constexpr ((DW_PIN_CONSTS & 1) != 0) asm volatile("" : "+v"(P1.c0l), "+v"(P2.c0l));
+        if constexpr ((DW_PIN_CONSTS & 2) != 0) { asm volatile("" : "+v"(P1.pck)); P2.pck = P1.pck; }
+        if constexpr ((DW_PIN_CONSTS & 4) != 0) { asm volatile("" : "+v"(P1.eKb)); P2.eKb = P1.eKb; }
+        if constexpr ((DW_PIN_CONSTS & 8) != 0) { asm volatile("" : "+v"(P1.gt)); P2.gt = P1.gt; }
+    }
     float st_m1 = 0.f;                                          // STATS accumulators of this lane
     unsigned int st_c2 = 0, st_nmm = 0;
     // one row of the map with coefficient set P: (up, mid, down) -> new values; exact mode also queues
     // the near-tie cells (kind 1 = step 1, 2 = step 2; lrow = row index relative to grid row r0-2)
     auto row_map = [&](const PhysF32& P, const Row4& upL, const Row4& miL, const Row4& dnL, const Row4& upD,
-                       const Row4& miD, const Row4& dnD, float4& nl, float4& nd, int kind, int lrow, const bool* use,
-                       float* sure_max = nullptr) {
+                       const Row4& miD, const Row4& dnD, float4& nl, float4& nd, int kind, int lrow,
+                       const TieT* use, float* sure_max = nullptr) {
         float ol[4], od[4];
-        bool tie[4];
-        cells4<EXACT>(P, upL, miL, dnL, upD, miD, dnD, ol, od, tie);
+        TieT tie[4];
+        cells4<EXACT, SYM, TieT>(P, upL, miL, dnL, upD, miD, dnD, ol, od, tie);
         if (EXACT) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) tie[i] = tie[i] && use[i];
+            for (int i = 0; i < 4; ++i) tie[i] = tie[i] & use[i];
         }
         if (STATS && sure_max) {                                 // max over the cells whose float32 value is certain
             float m = 0.f;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) m = fmaxf(m, (EXACT && tie[i]) ? 0.f : fmaxf(ol[i], od[i]));
+            for (int i = 0; i < 4; ++i) m = fmaxf(m, (EXACT && tie_lane(tie[i])) ? 0.f : fmaxf(ol[i], od[i]));
             *sure_max = m;
         }
         nl = make_float4(ol[0], ol[1], ol[2], ol[3]);
         nd = make_float4(od[0], od[1], od[2], od[3]);
-        if (EXACT && __ballot(tie[0] || tie[1] || tie[2] || tie[3]) != 0ull) {
+        if (EXACT && tie_mask(TieT(tie[0] | tie[1] | tie[2] | tie[3])) != 0ull) {
             queue_tie<0>(tie[0], nq, q, (unsigned)G.qcap, kind, lrow, 4 * lane, upL, miL, dnL, upD, miD, dnD, ol, od);
             queue_tie<1>(tie[1], nq, q, (unsigned)G.qcap, kind, lrow, 4 * lane, upL, miL, dnL, upD, miD, dnD, ol, od);
             queue_tie<2>(tie[2], nq, q, (unsigned)G.qcap, kind, lrow, 4 * lane, upL, miL, dnL, upD, miD, dnD, ol, od);
@@ -263,30 +291,31 @@ __device__ __forceinline__ void fused2_body(const TI* __restrict__ inL, const TI
     };
     // the same in two halves (LAG: the cells of both steps first, then their queue pushes)
     auto row_cells = [&](const PhysF32& P, const Row4& upL, const Row4& miL, const Row4& dnL, const Row4& upD,
-                         const Row4& miD, const Row4& dnD, float* ol, float* od, bool* tie, const bool* use,
-                         float* sure_max = nullptr) {
-        cells4<EXACT>(P, upL, miL, dnL, upD, miD, dnD, ol, od, tie);
+                         const Row4& miD, const Row4& dnD, float* ol, float* od, TieT* tie,
+                         const TieT* use, float* sure_max = nullptr) {
+        cells4<EXACT, SYM, TieT>(P, upL, miL, dnL, upD, miD, dnD, ol, od, tie);
         if (EXACT) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) tie[i] = tie[i] && use[i];
+            for (int i = 0; i < 4; ++i) tie[i] = tie[i] & use[i];
         }
         if (STATS && sure_max) {                                 // max over the cells whose float32 value is certain
             float m = 0.f;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) m = fmaxf(m, (EXACT && tie[i]) ? 0.f : fmaxf(ol[i], od[i]));
+            for (int i = 0; i < 4; ++i) m = fmaxf(m, (EXACT && tie_lane(tie[i])) ? 0.f : fmaxf(ol[i], od[i]));
             *sure_max = m;
         }
     };
     auto row_queue = [&](const Row4& upL, const Row4& miL, const Row4& dnL, const Row4& upD, const Row4& miD,
-                         const Row4& dnD, const float* ol, const float* od, const bool* tie, int kind, int lrow) {
-        if (EXACT && __ballot(tie[0] || tie[1] || tie[2] || tie[3]) != 0ull) {
+                         const Row4& dnD, const float* ol, const float* od, const TieT* tie, int kind,
+                         int lrow) {
+        if (EXACT && tie_mask(TieT(tie[0] | tie[1] | tie[2] | tie[3])) != 0ull) {
             queue_tie<0>(tie[0], nq, q, (unsigned)G.qcap, kind, lrow, 4 * lane, upL, miL, dnL, upD, miD, dnD, ol, od);
             queue_tie<1>(tie[1], nq, q, (unsigned)G.qcap, kind, lrow, 4 * lane, upL, miL, dnL, upD, miD, dnD, ol, od);
             queue_tie<2>(tie[2], nq, q, (unsigned)G.qcap, kind, lrow, 4 * lane, upL, miL, dnL, upD, miD, dnD, ol, od);
             queue_tie<3>(tie[3], nq, q, (unsigned)G.qcap, kind, lrow, 4 * lane, upL, miL, dnL, upD, miD, dnD, ol, od);
         }
     };
-    const bool use2[4] = {writes, writes, writes, writes};
+    const TieT use2[4] = {writes_m, writes_m, writes_m, writes_m};
 
     // windows: IL/ID input rows, SL/SD step-1 rows; slot of row index j (0 = row r0-2) is j % 3
     Row4 IL[3], ID[3], SL[3], SD[3];
@@ -322,14 +351,14 @@ __device__ __forceinline__ void fused2_body(const TI* __restrict__ inL, const TI
             if (do1) nx = load_raw(r0 + j);                        // input row j+2, needed by the NEXT iteration
             __builtin_amdgcn_sched_barrier(0);
             float l1[4], d1[4], l2[4], d2[4];
-            bool tie1[4], tie2[4];
+            TieT tie1[4], tie2[4];
             float sm1 = 0.f, sm2 = 0.f;
             if (do2)
                 row_cells(P2, SL[u], SL[(u + 1) % 3], SL[(u + 2) % 3], SD[u], SD[(u + 1) % 3], SD[(u + 2) % 3], l2, d2, tie2,
                           use2, STATS ? &sm2 : nullptr);
             if (do1)
                 row_cells(P1, IL[(u + 2) % 3], IL[u], IL[(u + 1) % 3], ID[(u + 2) % 3], ID[u], ID[(u + 1) % 3], l1, d1, tie1,
-                          need1, STATS ? &sm1 : nullptr);
+                          need1m, STATS ? &sm1 : nullptr);
             if (do2) {
                 row_queue(SL[u], SL[(u + 1) % 3], SL[(u + 2) % 3], SD[u], SD[(u + 1) % 3], SD[(u + 2) % 3], l2, d2, tie2, 2,
                           j - 2);
@@ -383,7 +412,7 @@ __device__ __forceinline__ void fused2_body(const TI* __restrict__ inL, const TI
             __builtin_amdgcn_sched_barrier(0);
             float4 l1, d1;
             float sm = 0.f;
-            row_map(P1, IL[(u + 2) % 3], IL[u], IL[(u + 1) % 3], ID[(u + 2) % 3], ID[u], ID[(u + 1) % 3], l1, d1, 1, j, need1,
+            row_map(P1, IL[(u + 2) % 3], IL[u], IL[(u + 1) % 3], ID[(u + 2) % 3], ID[u], ID[(u + 1) % 3], l1, d1, 1, j, need1m,
                     STATS ? &sm : nullptr);
             if (STATS && writes && j >= 2 && j <= nr + 1) st_m1 = fmaxf(st_m1, sm);   // step-1 rows of MY output cells
             to_rows4(l1, d1, SL[u], SD[u]);                        // step-1 row j replaces step-1 row j-3
@@ -486,7 +515,7 @@ __device__ __forceinline__ void fused2_body(const TI* __restrict__ inL, const TI
                         outD[off] = (TO)(float)kd;
                     }
                 }
-                const unsigned long long mask = __ballot(mism);
+                const unsigned long long mask = lane_mask(mism);
                 if (mism) {
                     const unsigned int slot = nmm + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
                                                                              __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
@@ -558,6 +587,7 @@ __device__ __forceinline__ void fused2_body(const TI* __restrict__ inL, const TI
                 }
             }
         } else {
+            report_overflow(ovf, ovf_seq, lane);                 // the host shortens the strips of the next launches
             // overflow fallback: every output cell of the strip, two float64 steps from the inputs
             // (RING: plus the column on either side, whose step-2 values depend on this wave's - unverified - step-1 edge)
             const int ncol = ROT ? 256 : (RING ? 258 : 248);
@@ -661,16 +691,17 @@ struct FusedExactArgs {
     unsigned long long* zero_me; int zero_n;
     unsigned int* pstats; float thr_hi;                           // STATS variants only
     PhysF64 P64; double La; double Lb;                            // cold (see kernarg_struct)
+    unsigned int* ovf; unsigned int ovf_seq;                      // cold: where a queue overflow is reported (host memory)
 };
 
-template <int MODE, bool PACK = false, bool STATS = false>
+template <int MODE, bool PACK = false, bool STATS = false, bool SYM = false>
 __global__ __launch_bounds__(256)
 __attribute__((amdgpu_waves_per_eu(fused_exact_waves<MODE, PACK, STATS>(), fused_exact_waves<MODE, PACK, STATS>())))
 void step_stream_fused2_exact(FusedExactArgs A) {
     const FusedExactArgs& cold = kernarg_struct<FusedExactArgs>();
     const PhysF32 P2 = with_lum(A.P1, A.lum2);
-    fused2_body<MODE, true, PACK, STATS>(A.inL, A.inD, A.outL, A.outD, A.G, A.P1, P2, cold.P64, cold.La, cold.Lb, A.zero_me,
-                                        A.zero_n, A.pstats, A.thr_hi);
+    fused2_body<MODE, true, PACK, STATS, SYM>(A.inL, A.inD, A.outL, A.outD, A.G, A.P1, P2, cold.P64, cold.La, cold.Lb, A.zero_me,
+                                             A.zero_n, A.pstats, A.thr_hi, &cold.ovf, &cold.ovf_seq);
 }
 
 }  // namespace dw

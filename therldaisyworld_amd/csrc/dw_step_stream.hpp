@@ -55,6 +55,11 @@ struct Raw {                  // one row AS LOADED (binary16: 6 VGPRs; widened w
     plane_t hl, hd;           // halo column values - lanes 0-31: column left of the strip; lanes 32-63: right of it
 };
 
+// the lanes for which a condition holds, as a 64-bit mask.  The condition is the result of vector compares, i.e.
+// already a lane mask in a scalar register pair: the intrinsic on the bool itself is that mask and-ed with exec
+// (HIP's __ballot(int) first widens the bool to an int: a v_cndmask + v_cmp_ne pair per call in the hot loop).
+__device__ __forceinline__ unsigned long long lane_mask(bool c) { return __builtin_amdgcn_ballot_w64(c); }
+
 constexpr int kDppWaveShl1 = 0x130, kDppWaveRol1 = 0x134, kDppWaveShr1 = 0x138, kDppWaveRor1 = 0x13C;
 
 template <int CTRL>
@@ -154,14 +159,30 @@ __device__ __forceinline__ void wait_row_stores_before_patching() {
     __builtin_amdgcn_s_waitcnt(0x0F70);                        // gfx9 encoding: vmcnt(0), expcnt / lgkmcnt untouched
 }
 
-template <int I>
-__device__ __forceinline__ void queue_tie(bool tie, unsigned int& n, uint4* __restrict__ q, unsigned int cap, int b,
-                                          int row, int colq,
+// Tie flags come in two forms: the wave's 64-bit LANE MASK (wave-uniform: the and with the "cell matters" mask, the
+// skip tests, the slot numbering and the count all run on the scalar unit - the form of every kernel that has the
+// scalar registers for it) or one bool per lane (the STATS variants, which are at their register budget with it).
+__device__ __forceinline__ bool in_mask(unsigned long long mask) { return __builtin_amdgcn_inverse_ballot_w64(mask); }
+__device__ __forceinline__ bool tie_lane(unsigned long long mask) { return in_mask(mask); }    // is THIS lane flagged?
+__device__ __forceinline__ bool tie_lane(bool flag) { return flag; }
+__device__ __forceinline__ unsigned long long tie_mask(unsigned long long mask) { return mask; }
+__device__ __forceinline__ unsigned long long tie_mask(bool flag) { return lane_mask(flag); }
+
+// A wave whose repair queue overflowed tells the host (one word of page-locked host memory, written through: the
+// host reads it without synchronising, dw_api.hip adapt_strip_rows).  `ovf` / `seq` point into the kernarg segment:
+// read only here, on the cold path.
+__device__ __forceinline__ void report_overflow(unsigned int* const* ovf, const unsigned int* seq, int lane) {
+    if (ovf && *ovf && lane == 0) __hip_atomic_store(*ovf, *seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+template <int I, typename F>
+__device__ __forceinline__ void queue_tie(F tie, unsigned int& n, uint4* __restrict__ q, unsigned int cap,
+                                          int b, int row, int colq,
                                           const Row4& upL, const Row4& miL, const Row4& dnL, const Row4& upD,
                                           const Row4& miD, const Row4& dnD, const float* ol, const float* od) {
-    const unsigned long long mask = __ballot(tie);
+    const unsigned long long mask = tie_mask(tie);
     if (mask == 0ull) return;                                   // wave-uniform
-    if (tie) {
+    if (tie_lane(tie)) {
         const unsigned int slot = n + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
                                                                 __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
         if (slot < cap) {
@@ -178,12 +199,13 @@ __device__ __forceinline__ void queue_tie(bool tie, unsigned int& n, uint4* __re
     n += (unsigned)__popcll(mask);
 }
 
-template <bool EXACT, int HALO, int RB>
+template <bool EXACT, int HALO, int RB, bool SYM = false>
 __device__ __forceinline__ void stream_body(const plane_t* __restrict__ inL, const plane_t* __restrict__ inD,
                                             plane_t* __restrict__ outL, plane_t* __restrict__ outD, const StripGeom& G,
                                             const PhysF32& P, const PhysF64& P64, StatsDev* __restrict__ stats,
                                             unsigned long long* __restrict__ fixups,
-                                            unsigned long long* __restrict__ zero_me, int zero_n) {
+                                            unsigned long long* __restrict__ zero_me, int zero_n,
+                                            unsigned int* const* ovf = nullptr, const unsigned int* ovf_seq = nullptr) {
     __shared__ uint4 s_queue[EXACT ? 4 * kWaveQueueCap * 3 : 1];
     const int bid = blockIdx.x;
     const int wg = (bid & 7) * G.chunk + (bid >> 3);            // XCD-aware: contiguous run per XCD
@@ -211,6 +233,7 @@ __device__ __forceinline__ void stream_body(const plane_t* __restrict__ inL, con
     const int ncq = PACK ? 64 : min(64, (G.W - c0) >> 2);   // active lanes (4 columns each)
     const int last_lane = ncq - 1;
     const bool active = PACK ? (pw < G.wpr && b * G.wpr + pw < G.B) : lane < ncq;
+    const unsigned long long active_mask = lane_mask(active);
     const size_t woff = (size_t)world * G.H * G.W;
     const int colq = PACK ? 4 * pj : c0 + 4 * min(lane, last_lane);   // inactive lanes shadow the last active one
     int hcol = lane < 32 ? c0 - 1 : c0 + 4 * ncq;           // halo column of this lane's half-wave
@@ -252,13 +275,13 @@ __device__ __forceinline__ void stream_body(const plane_t* __restrict__ inL, con
     auto row_math = [&](const Row4& upL, const Row4& miL, const Row4& dnL, const Row4& upD, const Row4& miD,
                         const Row4& dnD, int k) {
         float ol[4], od[4];
-        bool tie[4];
-        cells4<EXACT>(P, upL, miL, dnL, upD, miD, dnD, ol, od, tie);
+        unsigned long long tie[4];                          // lane masks (wave-uniform)
+        cells4<EXACT, SYM, unsigned long long>(P, upL, miL, dnL, upD, miD, dnD, ol, od, tie);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             if (EXACT) {
-                tie[i] = tie[i] && (HALO < 2 || active);
-                acc_max = fmaxf(acc_max, tie[i] ? 0.f : fmaxf(ol[i], od[i]));
+                if (HALO >= 2) tie[i] &= active_mask;
+                acc_max = fmaxf(acc_max, in_mask(tie[i]) ? 0.f : fmaxf(ol[i], od[i]));
             } else {
                 acc_max = fmaxf(acc_max, fmaxf(ol[i], od[i]));
             }
@@ -350,6 +373,7 @@ __device__ __forceinline__ void stream_body(const plane_t* __restrict__ inL, con
                 }
             }
         } else {                                            // queue overflow: the whole strip in float64
+            report_overflow(ovf, ovf_seq, lane);
             acc_max = 0.f; acc_l = 0.f; acc_d = 0.f;
             const int nc = PACK ? 256 : min(256, G.W - c0);
             for (int i = lane; i < nr * nc; i += 64) {
@@ -448,14 +472,15 @@ struct StreamExactArgs {
     const plane_t* inL; const plane_t* inD; plane_t* outL; plane_t* outD;
     StripGeom G; PhysF32 P; StatsDev* stats; unsigned long long* fixups; unsigned long long* zero_me; int zero_n;
     PhysF64 P64;                                                  // cold
+    unsigned int* ovf; unsigned int ovf_seq;                      // cold: where a queue overflow is reported
 };
 
-template <int HALO>
+template <int HALO, bool SYM = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DW_STREAM_WAVES_EXACT, DW_STREAM_WAVES_EXACT)))
 void step_stream_exact(StreamExactArgs A) {
-    stream_body<true, HALO, DW_STREAM_RB_EXACT>(A.inL, A.inD, A.outL, A.outD, A.G, A.P,
-                                                kernarg_struct<StreamExactArgs>().P64, A.stats, A.fixups, A.zero_me,
-                                                A.zero_n);
+    const StreamExactArgs& cold = kernarg_struct<StreamExactArgs>();
+    stream_body<true, HALO, DW_STREAM_RB_EXACT, SYM>(A.inL, A.inD, A.outL, A.outD, A.G, A.P, cold.P64, A.stats, A.fixups,
+                                                     A.zero_me, A.zero_n, &cold.ovf, &cold.ovf_seq);
 }
 
 }  // namespace dw

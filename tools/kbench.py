@@ -3,8 +3,9 @@
 of the library in ONE process (cdna_hip_programming.md §5.4 rule 24: boxes and even consecutive
 processes on one box differ by up to 10 %).
 
-usage: kbench.py B G precision[,precision] [--libs name=path,...] [--steps N] [--rounds R]
-       env DW_* overrides are read by the library at handle creation."""
+usage: kbench.py B G precision[,precision] [--libs name=path[@ENV=V[;ENV=V]],...] [--steps N] [--rounds R]
+       env DW_* overrides are read by the library at handle creation; an arm's @ENV=V pairs are set only while
+       its handle is created (path may be empty: the default build)."""
 import argparse
 import os
 import statistics
@@ -28,10 +29,19 @@ if a.libs:
     libs = [tuple(x.split("=", 1)) for x in a.libs.split(",")]
 arms = []
 for prec in a.precisions.split(","):
-    for name, path in libs:
+    for name, spec in libs:
+        path, _, envs = (spec or "").partition("@")
+        over = dict(kv.split("=", 1) for kv in envs.split(";") if kv)
+        saved = {k: os.environ.get(k) for k in over}
+        os.environ.update(over)
         p = amd.default_params(a.B, a.G, a.G, a.agents)
         p.precision = _ffi.PRECISION[prec]
-        eng = amd.Engine(p, lib_path=path)
+        eng = amd.Engine(p, lib_path=path or None)
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
         eng.init_random(42)
         L = eng.step_n(220, 0.75, 0.75 / 512, 0.75, 1.5)      # developed state, L ~ 1.07
         arms.append((f"{name}/{prec}", eng, L, []))

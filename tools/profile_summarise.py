@@ -53,7 +53,10 @@ for prec in ("exact", "fast"):
     json.dump(line, open(os.path.join(root, "profiles", f"{tag}_bench_{wl}_{prec}.json"), "w"))
     fetch = counter_avg(find(f"pmc_{prec}_FETCH_SIZE/**/*counter_collection.csv"), "FETCH_SIZE")
     write = counter_avg(find(f"pmc_{prec}_WRITE_SIZE/**/*counter_collection.csv"), "WRITE_SIZE")
-    out = {"workload": wl, "precision": prec, "round": 2, "tag": tag, "plane_elem_bytes": 2, "shape": desc,
+    out = {"workload": wl, "precision": prec, "round": 3, "tag": tag, "plane_elem_bytes": 2, "shape": desc,
+           "worlds_per_gpu": cfg["worlds_per_gpu"], "grid": cfg["grid"],
+           "library_build_id": cfg.get("library_build_id"),         # bench.py flags the derived fields stale when
+                                                                      # the live library was built from other sources
            "command": f"bench.py --workload {wl} --precision {prec} (tools/profile_round.sh)"}
     for label, names, steps in (("fused", [k for k in fetch if "fused2" in k], 2),
                                 ("single", [k for k in fetch if "step_stream" in k and "fused2" not in k], 1)):
@@ -91,7 +94,9 @@ for prec in ("exact", "fast"):
           f"avg {main.get('rocprofv3_kernel_avg_ns', 0) / 1e6:.4f} ms")
     # ---- SQ counters of the fused kernel
     if valu_out is None:
-        valu_out = {"round": 2, "tag": tag, "workload": desc, "plane_elem_bytes": 2,
+        valu_out = {"round": 3, "tag": tag, "workload": desc, "plane_elem_bytes": 2,
+                    "library_build_id": cfg.get("library_build_id"), "worlds_per_gpu": cfg["worlds_per_gpu"],
+                    "grid": cfg["grid"],
                     "note": "rocprofv3 --kernel-trace --pmc <two counters per pass>; per-launch averages over the dispatches "
                             "of the fused step-pair kernel; one launch = 2 steps = 2 * cells / 64 wave-cell-evaluations"}
     vals, kernel = {}, None
