@@ -96,19 +96,6 @@ struct dw_handle {
     StripGeom sgeom{};
     bool allow_fuse = false;          // wide grids: dw_step_n / dw_run_episode fuse pairs of steps
     bool fused_ring = false;          // W == 1024: the four waves of a workgroup form a ring over the torus row
-    // Exact mode, adaptive strip height: a wave whose repair queue overflows recomputes its whole strip
-    // in float64 (4-6x slower) and stores the launch's sequence number into `ovf` - one word of page-locked host
-    // memory the device writes through - which the host reads (no synchronisation) before the next exact launch:
-    // an overflow seen from a launch issued at the current height halves the height of the following launches
-    // (twice the queue room per cell); after `clean_needed` launches without one it is doubled again, and every
-    // relapse doubles that patience.
-    unsigned int* ovf_host = nullptr;
-    unsigned int* ovf_dev = nullptr;
-    unsigned int launch_seq = 0;      // sequence number of the last exact wave-strip launch
-    unsigned int sr_since_seq = 0;    // first launch issued at the current strip height
-    int sr_base = 0, sr_cur = 0;      // the height select_kernel chose / the height in use
-    int clean_launches = 0, clean_needed = 32;
-    bool adapt = false;
     bool sym_albedo = false;          // a_dark - a_bare == -(a_light - a_bare) exactly: the exact wave-strip kernels use
                                       // the two-term coefficient chain (growth_t<.., SYM>)
     FusedGeom fgeom{};
@@ -413,10 +400,63 @@ static void derive_f32_pair(const dw_params& p, double L1, double L2, PhysF32* P
     P2->tie_lo = tie_lo;
 }
 
+// Error bound of the float32 map on an UN-quantised state (step_generic<In, 3>, dw_step_generic.hpp; the first step of
+// an episode in the exact mode).  Same chain of estimates as derive_f32's round-3 bound with: iota = u for a float64
+// state (its values are rounded to float32 on the way in; the float64 re-evaluation reads the originals), 0 for a
+// float32 state; stencil sums of non-integers round (2u per sum of four, 3u for the sum of eight); the density
+// carries 5u + iota; the coefficient chain is the rounded one (no exact hi part): its absolute error is
+// (8u + iota) M + u |c0| with the per-cell M the kernel evaluates.
+static FirstStepBound derive_first_bound(const dw_params& p, double L, const PhysF32& P, bool from_f64) {
+    const double u = std::ldexp(1.0, -24), iota = from_f64 ? u : 0.0;
+    const double kmax = 1000.0;
+    const double To4 = std::pow(p.temp_optimal, 4), K = p.S * L / p.sigma;
+    const double e0 = K * (1.0 - p.albedo_bare * p.p) / To4 - 1.0;
+    const double c0l = e0 + p.q2 * (p.albedo_bare * p.p - p.albedo_light) / To4;
+    const double c0d = e0 + p.q2 * (p.albedo_bare * p.p - p.albedo_dark) / To4;
+    const double a1 = std::fabs((double)P.a1), a2 = std::fabs((double)P.a2), a3 = std::fabs((double)P.a3), a4 = std::fabs((double)P.a4);
+    const double c0m = std::fmax(std::fabs(c0l), std::fabs(c0d));
+    // admissible interval of e (both covers may be full in the same cell) and the worst-case absolute error of e
+    const double pos = (std::fmax((double)P.a1, 0.0) + std::fmax((double)P.a2, 0.0)) * 8 * kmax +
+                       (std::fmax((double)P.a3, 0.0) + std::fmax((double)P.a4, 0.0)) * kmax;
+    const double neg = (std::fmin((double)P.a1, 0.0) + std::fmin((double)P.a2, 0.0)) * 8 * kmax +
+                       (std::fmin((double)P.a3, 0.0) + std::fmin((double)P.a4, 0.0)) * kmax;
+    const double emax = std::fmax(c0l, c0d) + pos, emin = std::fmin(c0l, c0d) + neg;
+    const double Mmax = (a1 + a2) * 8 * kmax + (a3 + a4) * kmax;
+    const double de_max = (8.0 * u + iota) * Mmax + u * c0m;
+    const double vmin = 1.0 + emin, vmax = 1.0 + emax;
+    const bool admissible = vmin > 0.02;
+    const double vlo = std::fmax(vmin, 0.02);
+    const double smax = std::sqrt(std::fmax(vmax, vlo)), ymax = std::sqrt(smax);
+    const double sg = smax / (smax + 1.0), et = ymax / (ymax + 1.0);
+    const double re = std::fmax(std::fabs(emin) / vlo, std::fabs(emax) / std::fmax(vmax, vlo));
+    const double ev = u * (1.0 + re) + de_max / vlo;
+    const double eD = 3.0 * u + (0.5 * ev + 2.0 * u) * sg + (0.25 * ev + 3.0 * u) * et;
+    const double ew = 4.0 * u + eD;
+    const double kbe = cbeta_host(p);
+    const double Dmin = kbe * (std::sqrt(std::sqrt(vlo)) + 1.0) * (std::sqrt(vlo) + 1.0);
+    const double kbmax = std::fmax(std::fabs(p.p), std::fabs(p.p - 2.0));
+    const double pu = (double)(float)p.p == p.p ? 0.0 : std::fabs(p.p);
+    const double safety = 1.0 + 0x1p-7;
+    const double kK = 5.0 * u + iota;                             // relative error of a density
+    auto up = [](double v) { float f = (float)v; return (double)f < v ? std::nextafterf(f, INFINITY) : f; };
+    FirstStepBound B;
+    B.a1 = up(a1); B.a2 = up(a2); B.a3 = up(a3); B.a4 = up(a4);
+    B.c_de = up(safety * (8.0 * u + iota) * (1.0 + 8.0 * u));     // (1 + 8u): M itself is a float32 chain
+    B.c_c0 = up(safety * u * c0m);
+    // |kb^ - kb| <= pu + (kK + 2u)|p| + (kK + 3u)|kb| [kb < 0];  |gq^ - gq| <= |K| |f^ - f| + (kK + u)|gq|
+    B.eK0 = up(safety * (pu + (kK + 2.0 * u) * std::fabs(p.p) + kbmax * u + ((kK + 3.0 * u) + u) * std::fabs(p.gamma)));
+    B.eK1 = up(safety * (pu + (kK + 2.0 * u) * std::fabs(p.p) + kbmax * (u + 2.0 * ew)));
+    B.cW = up(safety * 2.0 * kbmax / Dmin);                       // 2 de |e| / D^2 <= 2 de |w| / Dmin
+    B.eA = up(safety * ((kK + 3.0 * u) + u + (kK + u)));
+    B.cS = up(safety * u);                                        // the sum k + gq rounds (u |sum|); a float64 k was rounded (u k)
+    B.slack = admissible ? 4e-6f : 1.0f;                          // the float32 arithmetic of eps itself; inadmissible: all float64
+    return B;
+}
+
 // ------------------------------------------------------------------------------------------------
 // kernel selection
 // ------------------------------------------------------------------------------------------------
-// strip counts / grid sizes of the wave-strip kernels for strips of `sr` rows (select_kernel; adapt_strip_rows)
+// strip counts / grid sizes of the wave-strip kernels for strips of `sr` rows
 static void set_strip_rows(dw_handle* h, int sr) {
     const dw_params& p = h->prm;
     StripGeom& g = h->sgeom;
@@ -431,29 +471,6 @@ static void set_strip_rows(dw_handle* h, int sr) {
     f.nstrips = (int)(groups * f.nrs * f.ncs);
     f.nwg = h->fused_ring ? f.nstrips : (f.nstrips + 3) / 4;
     f.chunk = (f.nwg + 7) / 8;
-    h->sr_cur = g.SR;
-}
-
-// Called before every exact wave-strip launch: react to the overflow word (see dw_handle) and hand out the
-// launch's sequence number.
-static unsigned int adapt_strip_rows(dw_handle* h) {
-    const unsigned int seq = ++h->launch_seq;
-    if (!h->adapt || !h->ovf_host) return seq;
-    const unsigned int seen = *reinterpret_cast<volatile unsigned int*>(h->ovf_host);
-    const bool overflowed = seen != 0 && (int)(seen - h->sr_since_seq) >= 0;     // by a launch at the current height
-    if (overflowed) {
-        h->clean_launches = 0;
-        if (h->sr_cur > 8) {
-            set_strip_rows(h, h->sr_cur / 2);
-            h->sr_since_seq = seq;
-            if (h->clean_needed < 4096) h->clean_needed *= 2;
-        }
-    } else if (h->sr_cur < h->sr_base && ++h->clean_launches >= h->clean_needed) {
-        set_strip_rows(h, h->sr_cur * 2 < h->sr_base ? h->sr_cur * 2 : h->sr_base);
-        h->sr_since_seq = seq;
-        h->clean_launches = 0;
-    }
-    return seq;
 }
 
 static void select_kernel(dw_handle* h) {
@@ -497,10 +514,6 @@ static void select_kernel(dw_handle* h) {
             if (const char* e = std::getenv("DW_STRIP_ROWS")) { const int v = std::atoi(e); if (v >= 1) sr = v; }
             g.SR = p.height < sr ? p.height : sr;
         }
-        h->sr_base = h->sr_cur = g.SR;
-        h->sr_since_seq = h->launch_seq + 1;
-        h->clean_launches = 0;
-        h->adapt = !std::getenv("DW_NO_ADAPT") && !std::getenv("DW_STRIP_ROWS");
         g.qcap = kWaveQueueCap;
         int mcap = kMismatchCap;
         if (const char* e = std::getenv("DW_TEST_QUEUE_CAP")) {  // tests: force the overflow fallbacks
@@ -618,9 +631,24 @@ static int launch_forward(dw_handle* h, double L) {
 #define DW_GEN(T, PR, IL, ID)                                                                                     \
     hipLaunchKernelGGL((step_generic<T, PR>), ggrid, dim3(256), 0, h->stream, IL, ID, h->L16[out], h->D16[out],   \
                        p.height, p.width, P, P64, stats, fixups, zero_me, zero_n, gcpt)
+        // exact mode: float32 with the tie bound for non-integer inputs, float64 only for the flagged cells
+        // (DW_FIRST_STEP_F64=1: every cell in float64, as in round 2 - experiments)
+        static const bool first_f64 = std::getenv("DW_FIRST_STEP_F64") != nullptr;
         const bool f32arith = prec == DW_PRECISION_FAST;
-        if (h->unq_kind == UNQ_F64) { if (f32arith) DW_GEN(double, 1, h->L64, h->D64); else DW_GEN(double, 2, h->L64, h->D64); }
-        else { if (f32arith) DW_GEN(float, 1, h->U32L, h->U32D); else DW_GEN(float, 2, h->U32L, h->U32D); }
+        const bool bounded = prec == DW_PRECISION_EXACT && !first_f64;
+#define DW_GEN3(T, IL, ID, FB)                                                                                    \
+    hipLaunchKernelGGL((step_generic<T, 3>), ggrid, dim3(256), 0, h->stream, IL, ID, h->L16[out], h->D16[out],    \
+                       p.height, p.width, P, P64, stats, fixups, zero_me, zero_n, gcpt, FB)
+        if (h->unq_kind == UNQ_F64) {
+            if (f32arith) DW_GEN(double, 1, h->L64, h->D64);
+            else if (bounded) DW_GEN3(double, h->L64, h->D64, derive_first_bound(p, L, P, true));
+            else DW_GEN(double, 2, h->L64, h->D64);
+        } else {
+            if (f32arith) DW_GEN(float, 1, h->U32L, h->U32D);
+            else if (bounded) DW_GEN3(float, h->U32L, h->U32D, derive_first_bound(p, L, P, false));
+            else DW_GEN(float, 2, h->U32L, h->U32D);
+        }
+#undef DW_GEN3
         HIPCHK(hipGetLastError());
     } else if (prec == DW_PRECISION_F64 || (h->tcq == 0 && !h->use_stream)) {
         if (prec == DW_PRECISION_F64) DW_GEN(plane_t, 2, h->L16[in], h->D16[in]);
@@ -630,7 +658,6 @@ static int launch_forward(dw_handle* h, double L) {
         HIPCHK(hipGetLastError());
     } else if (h->use_stream) {
         const bool ex = prec == DW_PRECISION_EXACT;
-        const unsigned int ovf_seq = ex ? adapt_strip_rows(h) : 0u;      // may change the strip height: before `g`
         const StripGeom& g = h->sgeom;
         const dim3 grid((unsigned)g.chunk * 8u);
         const int halo = p.width < 256 ? 3 : (p.width == 256 ? 0 : (p.width % 256 == 0 ? 1 : 2));
@@ -639,7 +666,7 @@ static int launch_forward(dw_handle* h, double L) {
                        h->D16[out], g, P, P64, stats, fixups, zero_me, zero_n)
         if (ex) {
             const StreamExactArgs A{h->L16[in], h->D16[in], h->L16[out], h->D16[out], g, P, stats, fixups, zero_me,
-                                    zero_n, P64, h->ovf_dev, ovf_seq};
+                                    zero_n, P64};
 #define DW_SX(HL)                                                                                     \
     do {                                                                                              \
         if (h->sym_albedo) hipLaunchKernelGGL((step_stream_exact<HL, true>), grid, dim3(256), 0, h->stream, A); \
@@ -647,6 +674,7 @@ static int launch_forward(dw_handle* h, double L) {
     } while (0)
             if (halo == 0) DW_SX(0); else if (halo == 1) DW_SX(1); else if (halo == 2) DW_SX(2); else DW_SX(3);
 #undef DW_SX
+
         } else {
             if (halo == 0) DW_STREAM(step_stream_fast, 0);
             else if (halo == 1) DW_STREAM(step_stream_fast, 1);
@@ -692,13 +720,12 @@ static int launch_forward_fused2(dw_handle* h, double L1, double L2, unsigned in
     else { P1 = derive_f32(p, L1); P2 = derive_f32(p, L2); }
     unsigned long long* zero_me = reinterpret_cast<unsigned long long*>(h->stats2[h->sp]);
     const int zero_n = (int)(h->stats_bytes / sizeof(unsigned long long));
-    const unsigned int ovf_seq = p.precision == DW_PRECISION_EXACT ? adapt_strip_rows(h) : 0u;   // before `g`
     const FusedGeom& g = h->fgeom;
     const dim3 grid((unsigned)g.chunk * 8u);
     const bool rot = p.width == 256, pack = p.width < 256, ring = h->fused_ring;
     if (p.precision == DW_PRECISION_EXACT) {
         const FusedExactArgs A{h->L16[in], h->D16[in], h->L16[out], h->D16[out], g, P1, lum_part(P2), zero_me, zero_n,
-                               pstats, thr_hi, make_f64(p, L1), L1, L2, h->ovf_dev, ovf_seq};
+                               pstats, thr_hi, make_f64(p, L1), L1, L2};
 #define DW_FX(R, P, S)                                                                                            \
     do {                                                                                                          \
         if (h->sym_albedo) hipLaunchKernelGGL((step_stream_fused2_exact<R, P, S, true>), grid, dim3(256), 0, h->stream, A); \
@@ -872,9 +899,6 @@ int dw_create(const dw_params* p, dw_handle** out) {
     TRY(hipMemsetAsync(h->agents_done_at, 0, sizeof(int) * bn, h->stream));
     TRY(hipMemsetAsync(h->n_alive, 0, sizeof(int), h->stream));
     TRY(hipMalloc(&h->side_stats, sizeof(StatsDev) * (p->batch + 1)));
-    TRY(hipHostMalloc(reinterpret_cast<void**>(&h->ovf_host), 64, hipHostMallocMapped));
-    *h->ovf_host = 0u;
-    TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->ovf_dev), h->ovf_host, 0));
     TRY(hipEventCreate(&h->ev0));
     TRY(hipEventCreate(&h->ev1));
     TRY(hipEventCreate(&h->evf0));
@@ -895,7 +919,6 @@ int dw_destroy(dw_handle* h) {
     (void)hipFree(h->idx); (void)hipFree(h->st); (void)hipFree(h->action); (void)hipFree(h->action_tmp);
     (void)hipFree(h->reward_d); (void)hipFree(h->done_d);
     if (h->pinned) (void)hipHostFree(h->pinned);
-    if (h->ovf_host) (void)hipHostFree(h->ovf_host);
     (void)hipFree(h->snapL); (void)hipFree(h->snapD); (void)hipFree(h->snap_idx); (void)hipFree(h->snap_st);
     (void)hipFree(h->snapPL); (void)hipFree(h->snapPD);
     (void)hipFree(h->snap_stats);

@@ -121,8 +121,7 @@ __device__ __forceinline__ void fused2_body(const TI* __restrict__ inL, const TI
                                             const PhysF32& P1_, const PhysF32& P2_, const PhysF64& P64,
                                             const double& La, const double& Lb,
                                             unsigned long long* __restrict__ zero_me, int zero_n,
-                                            unsigned int* __restrict__ pstats = nullptr, float thr_hi = 0.f,
-                                            unsigned int* const* ovf = nullptr, const unsigned int* ovf_seq = nullptr) {
+                                            unsigned int* __restrict__ pstats = nullptr, float thr_hi = 0.f) {
     // LAG: step 2 runs one row further behind step 1, on results of earlier iterations only (see below).
     // Measured: exact kernels -5...-11 %, packed float32 -6 %, W = 256 float32 -4 %,
     // overlapped strips -1.5 %.  (-DDW_FUSED_LAG=0 builds the dependent order for comparison.)
@@ -251,14 +250,18 @@ __device__ __forceinline__ void fused2_body(const TI* __restrict__ inL, const TI
     // fraction, the tie bracket's constant, tie_lo beside eA - were copied into VGPRs again and again (the compiler
     // rematerialises them per row map: ~1.1 v_mov per cell-evaluation).  Held in VGPRs for the whole strip instead.
 #ifndef DW_PIN_CONSTS
-#define DW_PIN_CONSTS 14
+#define DW_PIN_CONSTS -1                                        // per kernel variant (see PIN below)
 #endif
     PhysF32 P1 = P1_, P2 = P2_;
-    if constexpr (EXACT && DW_PIN_CONSTS != 0 && !STATS && !PACK) {   // bit mask: 1 c0l (both steps), 2 pck, 4 eKb, 8 gt
-        if constexpr ((DW_PIN_CONSTS & 1) != 0) asm volatile("" : "+v"(P1.c0l), "+v"(P2.c0l));
-        if constexpr ((DW_PIN_CONSTS & 2) != 0) { asm volatile("" : "+v"(P1.pck)); P2.pck = P1.pck; }
-        if constexpr ((DW_PIN_CONSTS & 4) != 0) { asm volatile("" : "+v"(P1.eKb)); P2.eKb = P1.eKb; }
-        if constexpr ((DW_PIN_CONSTS & 8) != 0) { asm volatile("" : "+v"(P1.gt)); P2.gt = P1.gt; }
+    // bit mask: 1 c0l (both steps), 2 pck, 4 eKb, 8 gt.  What fits without scratch traffic on the row loop's main path
+    // (tools/isa_report.py; the queue sweep inside the loop raised the pressure): overlapped strips 14, the ring 8,
+    // rotating strips none.
+    constexpr int PIN = DW_PIN_CONSTS < 0 ? (MODE == kFusedOvl ? 14 : (MODE == kFusedRing ? 8 : 0)) : DW_PIN_CONSTS;
+    if constexpr (EXACT && PIN != 0 && !STATS && !PACK) {
+        if constexpr ((PIN & 1) != 0) asm volatile("" : "+v"(P1.c0l), "+v"(P2.c0l));
+        if constexpr ((PIN & 2) != 0) { asm volatile("" : "+v"(P1.pck)); P2.pck = P1.pck; }
+        if constexpr ((PIN & 4) != 0) { asm volatile("" : "+v"(P1.eKb)); P2.eKb = P1.eKb; }
+        if constexpr ((PIN & 8) != 0) { asm volatile("" : "+v"(P1.gt)); P2.gt = P1.gt; }
     }
     float st_m1 = 0.f;                                          // STATS accumulators of this lane
     unsigned int st_c2 = 0, st_nmm = 0;
@@ -316,6 +319,98 @@ __device__ __forceinline__ void fused2_body(const TI* __restrict__ inL, const TI
         }
     };
     const TieT use2[4] = {writes_m, writes_m, writes_m, writes_m};
+
+    // ---- F1 + F2: the float64 sweep over this wave's queue (exact kernels) -------------------------------------
+    // Runs when the strip is finished AND whenever the queue is half full (`flush_at`): the queue never overflows
+    // on any state the dynamics produce, whatever the strip height (a strip whose queue did overflow lost entries
+    // and is recomputed whole in float64 - tens of times slower, which is why it must not happen), and the sweeps
+    // run on densely filled lanes.  Step-1 entries whose float32 value was wrong go to the mismatch list, which
+    // lives until the end of the strip (F3 needs every output row stored); step-2 entries patch rows this wave has
+    // already stored.
+    unsigned int nmm = 0;                                       // step-1 mismatches so far (wave-uniform)
+    bool redo = false;                                          // queue or mismatch list overflowed: whole strip in float64
+    const int flush_at = G.qcap >> 1;
+    auto world_of = [&](int lc) -> int {
+        return PACK ? min(b * G.wpr + min((lc >> 2) / G.lpw, G.wpr - 1), G.B - 1) : b;
+    };
+    // grid coordinates of a local (row, column)
+    auto grid_rc = [&](int lrow, int lc, int& gr, int& gc) {
+        gr = r0 - 2 + lrow;
+        gr = gr < 0 ? gr + G.H : (gr >= G.H ? gr - G.H : gr);
+        gc = c00 + lc;
+        gc = gc < 0 ? gc + G.W : (gc >= G.W ? gc - G.W : gc);
+    };
+    // world base and grid coordinates of a local (row, column); false if the column's world is missing
+    auto locate = [&](int lrow, int lc, size_t& wo, int& gr, int& gc) -> bool {
+        grid_rc(lrow, lc, gr, gc);
+        wo = world_off(lc);
+        if (!PACK) return true;
+        const int pwc = (lc >> 2) / G.lpw;
+        gc = lc - pwc * G.W;
+        return pwc < G.wpr && b * G.wpr + pwc < G.B;
+    };
+    // is local (row, column) an output cell of this wave?
+    auto is_output = [&](int lrow, int lc) -> bool {
+        if (lrow < 2 || lrow > nr + 1) return false;
+        if (PACK) return (lc >> 2) / G.lpw < G.wpr && b * G.wpr + (lc >> 2) / G.lpw < G.B;
+        if (ROT || RING) return true;                        // RING: also the two columns beside the wave's own
+        const int ln = lc >> 2;
+        return lc >= 4 && lc < 252 && cs * 248 + 4 * (ln - 1) < G.W;
+    };
+    auto sweep_queue = [&]() {
+        if (nq > (unsigned)G.qcap) redo = true;                 // entries were dropped
+        if (!redo && nq) {
+            wait_row_stores_before_patching();                  // F2 patches rows this wave stored
+            // the cold float64 constants come from the kernarg segment HERE (an opaque copy of the reference keeps
+            // the loads inside this rarely executed block instead of in scalar registers across the row loop)
+            const PhysF64* p64 = &P64;
+            const double* pLa = &La;
+            const double* pLb = &Lb;
+            asm volatile("" : "+s"(p64), "+s"(pLa), "+s"(pLb));
+            PhysF64 Pe = *p64;
+            const double la = *pLa, lb = *pLb;
+            for (unsigned int base = 0; base < nq; base += 64) {
+                const unsigned int e = base + lane;
+                bool mism = false;
+                unsigned int where = 0;
+                if (e < nq) {
+                    const uint4 e0 = q[e * 3], e1 = q[e * 3 + 1], e2 = q[e * 3 + 2];
+                    const unsigned int w[9] = {unpack_ld(e0.z), unpack_ld(e0.w), unpack_ld(e1.x),
+                                               unpack_ld(e1.y), unpack_ld(e1.z), unpack_ld(e1.w),
+                                               unpack_ld(e2.x), unpack_ld(e2.y), unpack_ld(e2.z)};
+                    Pe.L = e0.x == 1u ? la : lb;
+                    const NewCoverF64 o = cell_f64_lean(Pe, w);
+                    const unsigned int kl = (unsigned)dw_round3_k(o.nl), kd = (unsigned)dw_round3_k(o.nd);
+                    where = e0.y;
+                    if (e0.x == 1u) {
+                        mism = (kl | (kd << 16)) != unpack_ld(e2.w);
+                        if (STATS && is_output((int)(where >> 16), (int)(where & 0xffffu))) {   // exact value of a tie cell
+                            const unsigned int mx = kl > kd ? kl : kd;
+                            if (PACK) atomicMax(&pstats[2 * world_of((int)(where & 0xffffu))], mx);   // any world of the row
+                            else st_m1 = fmaxf(st_m1, (float)mx);              // my wave's world: reduced below
+                        }
+                    } else {
+                        int gr, gc;
+                        size_t wo;
+                        locate((int)(where >> 16), (int)(where & 0xffffu), wo, gr, gc);
+                        const size_t off = wo + (size_t)gr * G.W + gc;
+                        outL[off] = (TO)(float)kl;
+                        outD[off] = (TO)(float)kd;
+                    }
+                }
+                const unsigned long long mask = lane_mask(mism);
+                if (mism) {
+                    const unsigned int slot = nmm + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                                             __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                    if (slot < (unsigned)G.mcap) mm[slot] = where;
+                }
+                nmm += (unsigned)__popcll(mask);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the queue is reused: reads above before later pushes
+            __builtin_amdgcn_wave_barrier();
+        }
+        nq = 0;
+    };
 
     // windows: IL/ID input rows, SL/SD step-1 rows; slot of row index j (0 = row r0-2) is j % 3
     Row4 IL[3], ID[3], SL[3], SD[3];
@@ -396,6 +491,9 @@ __device__ __forceinline__ void fused2_body(const TI* __restrict__ inL, const TI
             iter(U1{}, Yes{}, Yes{}, j);
             iter(U2{}, Yes{}, Yes{}, j + 1);
             iter(U0{}, Yes{}, Yes{}, j + 2);
+            // wave-uniform and rare (see sweep_queue); not in the STATS variants, which are at their register budget: their
+            // live values would spill on the main path (they keep one sweep at the end of the strip)
+            if (EXACT && !STATS && __builtin_expect(nq >= (unsigned)flush_at, 0)) sweep_queue();
         }
         if (j <= jend) { iter(U1{}, Yes{}, Yes{}, j); ++j; }
         if (j <= jend) { iter(U2{}, Yes{}, Yes{}, j); ++j; }
@@ -445,86 +543,16 @@ __device__ __forceinline__ void fused2_body(const TI* __restrict__ inL, const TI
         PhysF64 Pa = P64, Pb = P64;
         Pa.L = La;
         Pb.L = Lb;
-        // grid coordinates of a local (row, column)
-        auto grid_rc = [&](int lrow, int lc, int& gr, int& gc) {
-            gr = r0 - 2 + lrow;
-            gr = gr < 0 ? gr + G.H : (gr >= G.H ? gr - G.H : gr);
-            gc = c00 + lc;
-            gc = gc < 0 ? gc + G.W : (gc >= G.W ? gc - G.W : gc);
-        };
-        auto world_of = [&](int lc) -> int {
-            return PACK ? min(b * G.wpr + min((lc >> 2) / G.lpw, G.wpr - 1), G.B - 1) : b;
-        };
-        // world base and grid coordinates of a local (row, column); false if the column's world is missing
-        auto locate = [&](int lrow, int lc, size_t& wo, int& gr, int& gc) -> bool {
-            grid_rc(lrow, lc, gr, gc);
-            wo = world_off(lc);
-            if (!PACK) return true;
-            const int pwc = (lc >> 2) / G.lpw;
-            gc = lc - pwc * G.W;
-            return pwc < G.wpr && b * G.wpr + pwc < G.B;
-        };
-        // is local (row, column) an output cell of this wave?
-        auto is_output = [&](int lrow, int lc) -> bool {
-            if (lrow < 2 || lrow > nr + 1) return false;
-            if (PACK) return (lc >> 2) / G.lpw < G.wpr && b * G.wpr + (lc >> 2) / G.lpw < G.B;
-            if (ROT || RING) return true;                        // RING: also the two columns beside the wave's own
-            const int ln = lc >> 2;
-            return lc >= 4 && lc < 252 && cs * 248 + 4 * (ln - 1) < G.W;
-        };
-        unsigned int nmm = 0;
-        bool redo = nq > (unsigned)G.qcap;
         // RING: a mismatch of a step-1 cell in the wave's first / last column also feeds output cells of the ADJACENT
         // wave, and this wave repairs them (F3 / the fallback below): every row store of the workgroup must have
         // completed before any patch store, and every F2 patch (which may rest on a neighbour's mismatched value)
         // before any F3 patch - two workgroup barriers, each behind a wait for the wave's own stores.
-        if (RING || nq) wait_row_stores_before_patching();      // wave-uniform; F2 / F3 / the fallback patch stored rows
-        if (RING) __syncthreads();
-        if (!redo) {
-            // F1 + F2 in one sweep over the queue (the entries differ only in the luminosity of their
-            // float64 re-evaluation): a step-1 entry whose float32 value was wrong goes to the mismatch
-            // list; a step-2 entry (payload = float32 step-1 values) patches the output - cells next to a
-            // mismatch are overwritten by F3 below.
-            for (unsigned int base = 0; base < nq; base += 64) {
-                const unsigned int e = base + lane;
-                bool mism = false;
-                unsigned int where = 0;
-                if (e < nq) {
-                    const uint4 e0 = q[e * 3], e1 = q[e * 3 + 1], e2 = q[e * 3 + 2];
-                    const unsigned int w[9] = {unpack_ld(e0.z), unpack_ld(e0.w), unpack_ld(e1.x),
-                                               unpack_ld(e1.y), unpack_ld(e1.z), unpack_ld(e1.w),
-                                               unpack_ld(e2.x), unpack_ld(e2.y), unpack_ld(e2.z)};
-                    PhysF64 Pe = Pa;
-                    Pe.L = e0.x == 1u ? La : Lb;
-                    const NewCoverF64 o = cell_f64_lean(Pe, w);
-                    const unsigned int kl = (unsigned)dw_round3_k(o.nl), kd = (unsigned)dw_round3_k(o.nd);
-                    where = e0.y;
-                    if (e0.x == 1u) {
-                        mism = (kl | (kd << 16)) != unpack_ld(e2.w);
-                        if (STATS && is_output((int)(where >> 16), (int)(where & 0xffffu))) {   // exact value of a tie cell
-                            const unsigned int mx = kl > kd ? kl : kd;
-                            if (PACK) atomicMax(&pstats[2 * world_of((int)(where & 0xffffu))], mx);   // any world of the row
-                            else st_m1 = fmaxf(st_m1, (float)mx);              // my wave's world: reduced below
-                        }
-                    } else {
-                        int gr, gc;
-                        size_t wo;
-                        locate((int)(where >> 16), (int)(where & 0xffffu), wo, gr, gc);
-                        const size_t off = wo + (size_t)gr * G.W + gc;
-                        outL[off] = (TO)(float)kl;
-                        outD[off] = (TO)(float)kd;
-                    }
-                }
-                const unsigned long long mask = lane_mask(mism);
-                if (mism) {
-                    const unsigned int slot = nmm + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
-                                                                             __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                    if (slot < (unsigned)G.mcap) mm[slot] = where;
-                }
-                nmm += (unsigned)__popcll(mask);
-            }
-            redo = nmm > (unsigned)G.mcap;
+        if (RING) {
+            wait_row_stores_before_patching();
+            __syncthreads();
         }
+        sweep_queue();                                          // what the strip's last rows queued
+        if (nmm > (unsigned)G.mcap) redo = true;
         if (RING) {
             wait_row_stores_before_patching();
             __syncthreads();
@@ -587,7 +615,6 @@ __device__ __forceinline__ void fused2_body(const TI* __restrict__ inL, const TI
                 }
             }
         } else {
-            report_overflow(ovf, ovf_seq, lane);                 // the host shortens the strips of the next launches
             // overflow fallback: every output cell of the strip, two float64 steps from the inputs
             // (RING: plus the column on either side, whose step-2 values depend on this wave's - unverified - step-1 edge)
             const int ncol = ROT ? 256 : (RING ? 258 : 248);
@@ -691,7 +718,6 @@ struct FusedExactArgs {
     unsigned long long* zero_me; int zero_n;
     unsigned int* pstats; float thr_hi;                           // STATS variants only
     PhysF64 P64; double La; double Lb;                            // cold (see kernarg_struct)
-    unsigned int* ovf; unsigned int ovf_seq;                      // cold: where a queue overflow is reported (host memory)
 };
 
 template <int MODE, bool PACK = false, bool STATS = false, bool SYM = false>
@@ -701,7 +727,7 @@ void step_stream_fused2_exact(FusedExactArgs A) {
     const FusedExactArgs& cold = kernarg_struct<FusedExactArgs>();
     const PhysF32 P2 = with_lum(A.P1, A.lum2);
     fused2_body<MODE, true, PACK, STATS, SYM>(A.inL, A.inD, A.outL, A.outD, A.G, A.P1, P2, cold.P64, cold.La, cold.Lb, A.zero_me,
-                                             A.zero_n, A.pstats, A.thr_hi, &cold.ovf, &cold.ovf_seq);
+                                             A.zero_n, A.pstats, A.thr_hi);
 }
 
 }  // namespace dw

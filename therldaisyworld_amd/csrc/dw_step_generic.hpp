@@ -11,8 +11,23 @@ namespace dw {
 // wave issues ONE set of reduction atomics for all of them: with one set per 64 cells the first step of the
 // north-star shape (2.7e8 waves x 3 atomics on 1024 x 3 addresses) took 0.65 s in either arithmetic.
 // generic_cells_per_thread() picks cpt so that the launch still has a few thousand workgroups.
-// PREC: 0 exact, 1 fast, 2 f64.
+// PREC: 0 exact (quantised input), 1 fast, 2 f64, 3 exact from an UN-quantised input (the first step of an episode):
+// float32 with a tie bound for non-integer inputs (FirstStepBound), the flagged cells of a workgroup collected in
+// LDS and re-evaluated in float64 from the original inputs by densely packed lanes after the cell loop.
 // ---------------------------------------------------------------------------------------------
+// Error bound of the float32 map on NON-INTEGER inputs (no exact coefficient chain: every operation rounds).
+// Derived like the bound of the quantised case (dw_api.hip derive_f32) with these changes: the
+// inputs carry iota (u for a float64 state converted to float32, 0 for a float32 state), stencil sums 2u-3u, the
+// density 5u + iota, and the absolute error of e is (8u + iota) * M + u |c0| with the per-cell magnitude
+// M = |a1| Sl8 + |a2| Sd8 + |a3| li + |a4| di, which enters the growth curve as 2 de |e| / D^2 <= 2 de |w| / Dmin:
+//   eps = |K| (eK0 + eK1 om + cW de |w|) + eA |gq| + cS (|k + gq| + k) + slack
+struct FirstStepBound {
+    float a1, a2, a3, a4;         // |a_i| of the rounded coefficient set
+    float c_de, c_c0;             // de = c_de * M + c_c0
+    float eK0, eK1, cW, eA, cS, slack;
+};
+constexpr int kFirstListCap = 1024;   // flagged cells per workgroup held in LDS (overflow: evaluated in line)
+
 __host__ inline int generic_cells_per_thread(long long batch, long long cells_per_world) {
     long long cpt = batch * cells_per_world / (256LL * 8192);          // big jobs: still >= 8192 workgroups
     const long long few = cells_per_world / (256LL * 512);              // any job: <= 512 atomic sets per world
@@ -29,7 +44,13 @@ __global__ __launch_bounds__(256) void step_generic(const InT* __restrict__ inL,
                                                     StatsDev* __restrict__ stats,
                                                     unsigned long long* __restrict__ fixups,
                                                     unsigned long long* __restrict__ zero_me,
-                                                    int zero_n, int cpt = 1) {
+                                                    int zero_n, int cpt = 1, FirstStepBound FB = FirstStepBound{}) {
+    __shared__ unsigned int s_list[PREC == 3 ? kFirstListCap : 1];
+    __shared__ unsigned int s_nlist;
+    if (PREC == 3) {
+        if (threadIdx.x == 0) s_nlist = 0u;
+        __syncthreads();
+    }
     const int b = blockIdx.y;
     const size_t woff = (size_t)b * H * W;
     float mx = 0.f, suml = 0.f, sumd = 0.f;       // integers <= 1000 * cpt: exact in float32
@@ -40,7 +61,7 @@ __global__ __launch_bounds__(256) void step_generic(const InT* __restrict__ inL,
     const unsigned int ucell = (blockIdx.x * (unsigned int)cpt + it) * 256u + threadIdx.x;   // H*W < 2^31: no wrap
     const int cell = (int)ucell;
     float kl = 0.f, kd = 0.f;
-    bool fixed = false;
+    bool fixed = false, deferred = false;
     if (ucell < (unsigned int)(H * W)) {
         const int r = cell / W, c = cell - r * W;
         const InT* pl = inL + woff;
@@ -62,10 +83,41 @@ __global__ __launch_bounds__(256) void step_generic(const InT* __restrict__ inL,
             const float Ed = (DW_AT(pd, ru, c) + DW_AT(pd, rd, c)) + (DW_AT(pd, r, cl) + DW_AT(pd, r, cr));
             const float Cd = (DW_AT(pd, ru, cl) + DW_AT(pd, ru, cr)) + (DW_AT(pd, rd, cl) + DW_AT(pd, rd, cr));
 #undef DW_AT
-            const GrowthF32 g = growth_f32<PREC != 1 || kFastSplit>(P, li, di, El, Cl, Ed, Cd);
+            const GrowthF32 g = growth_f32<(PREC != 1 && PREC != 3) || kFastSplit>(P, li, di, El, Cl, Ed, Cd);
             if (PREC == 1) {
                 kl = finish_fast(li, g.dKl, g.fl);
                 kd = finish_fast(di, g.dKd, g.fd);
+            } else if (PREC == 3) {
+                // k' = rint(clip(k + gq)) is final unless k + gq lies within the cell's error bound of a rounding tie
+                // (or of the clip's corners, which are integers: ties of rint are the only discontinuities)
+                const float M = fmaf(FB.a4, di, fmaf(FB.a3, li, fmaf(FB.a2, Ed + Cd, FB.a1 * (El + Cl))));
+                const float de = fmaf(FB.c_de, M, FB.c_c0);
+                auto settle = [&](float k, float gq, float dK, float om, bool& tie) -> float {
+                    const float sum = k + gq;
+                    const float r = __builtin_rintf(sum);
+                    const float eps = fmaf(fabsf(dK), fmaf(FB.cW * de, __builtin_sqrtf(om), fmaf(FB.eK1, om, FB.eK0)),
+                                           fmaf(FB.eA, fabsf(gq), fmaf(FB.cS, fabsf(sum) + k, FB.slack)));
+                    tie = !(fabsf(sum - r) <= 0.5f - eps);          // NaN: flagged
+                    return fminf(fmaxf(r, 0.0f), 1000.0f);
+                };
+                bool tl, td;
+                kl = settle(li, g.gql, g.dKl, g.oml, tl);
+                kd = settle(di, g.gqd, g.dKd, g.omd, td);
+                if (tl || td) {
+                    const unsigned int slot = atomicAdd(&s_nlist, 1u);
+                    if (slot < (unsigned int)kFirstListCap) {
+                        s_list[slot] = ucell;                    // evaluated after the loop, by densely packed lanes
+                        deferred = true;
+                    } else {
+                        double l9[9], d9[9];
+                        gather9(pl, H, W, r, c, l9);
+                        gather9(pd, H, W, r, c, d9);
+                        const CellF64 o = cell_f64(P64, l9, d9);
+                        kl = (float)dw_round3_k(o.nl);
+                        kd = (float)dw_round3_k(o.nd);
+                    }
+                    fixed = true;
+                }
             } else {
                 bool tl, td;
                 kl = finish_exact(P, li, g.gql, g.dKl, g.oml, tl);
@@ -81,13 +133,36 @@ __global__ __launch_bounds__(256) void step_generic(const InT* __restrict__ inL,
                 }
             }
         }
+        if (PREC == 3 && deferred) { kl = 0.f; kd = 0.f; }      // written and counted by the pass below
+        else {
         outL[woff + cell] = (plane_t)kl;
         outD[woff + cell] = (plane_t)kd;
+        }
     }
     mx = fmaxf(mx, fmaxf(kl, kd));
     suml += kl;
     sumd += kd;
     nfixed += fixed ? 1u : 0u;
+    }
+    if (PREC == 3) {
+        // the workgroup's flagged cells, one per thread: float64 from the original inputs (ref staging: bit-identical
+        // to the reference's own first step), stored, and added to this thread's partial reductions
+        __syncthreads();
+        const unsigned int n = s_nlist < (unsigned int)kFirstListCap ? s_nlist : (unsigned int)kFirstListCap;
+        for (unsigned int i = threadIdx.x; i < n; i += 256) {
+            const int cell = (int)s_list[i];
+            const int r = cell / W, c = cell - r * W;
+            double l9[9], d9[9];
+            gather9(inL + woff, H, W, r, c, l9);
+            gather9(inD + woff, H, W, r, c, d9);
+            const CellF64 o = cell_f64(P64, l9, d9);
+            const float kl = (float)dw_round3_k(o.nl), kd = (float)dw_round3_k(o.nd);
+            outL[woff + cell] = (plane_t)kl;
+            outD[woff + cell] = (plane_t)kd;
+            mx = fmaxf(mx, fmaxf(kl, kd));
+            suml += kl;
+            sumd += kd;
+        }
     }
     // per-world reductions: wave shuffles, the four waves through LDS, then one set of atomics per workgroup
     // (same-address atomics cost ~100 ns each: they, not the arithmetic, bound this kernel on few-world jobs)

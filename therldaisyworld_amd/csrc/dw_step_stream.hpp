@@ -168,13 +168,6 @@ __device__ __forceinline__ bool tie_lane(bool flag) { return flag; }
 __device__ __forceinline__ unsigned long long tie_mask(unsigned long long mask) { return mask; }
 __device__ __forceinline__ unsigned long long tie_mask(bool flag) { return lane_mask(flag); }
 
-// A wave whose repair queue overflowed tells the host (one word of page-locked host memory, written through: the
-// host reads it without synchronising, dw_api.hip adapt_strip_rows).  `ovf` / `seq` point into the kernarg segment:
-// read only here, on the cold path.
-__device__ __forceinline__ void report_overflow(unsigned int* const* ovf, const unsigned int* seq, int lane) {
-    if (ovf && *ovf && lane == 0) __hip_atomic_store(*ovf, *seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
 template <int I, typename F>
 __device__ __forceinline__ void queue_tie(F tie, unsigned int& n, uint4* __restrict__ q, unsigned int cap,
                                           int b, int row, int colq,
@@ -204,8 +197,7 @@ __device__ __forceinline__ void stream_body(const plane_t* __restrict__ inL, con
                                             plane_t* __restrict__ outL, plane_t* __restrict__ outD, const StripGeom& G,
                                             const PhysF32& P, const PhysF64& P64, StatsDev* __restrict__ stats,
                                             unsigned long long* __restrict__ fixups,
-                                            unsigned long long* __restrict__ zero_me, int zero_n,
-                                            unsigned int* const* ovf = nullptr, const unsigned int* ovf_seq = nullptr) {
+                                            unsigned long long* __restrict__ zero_me, int zero_n) {
     __shared__ uint4 s_queue[EXACT ? 4 * kWaveQueueCap * 3 : 1];
     const int bid = blockIdx.x;
     const int wg = (bid & 7) * G.chunk + (bid >> 3);            // XCD-aware: contiguous run per XCD
@@ -332,32 +324,27 @@ __device__ __forceinline__ void stream_body(const plane_t* __restrict__ inL, con
         to_rows(use[0], WL[s0], WD[s0]);                    // rows kk+3, kk+4: window rows 2, 3 of the next block
         to_rows(use[1], WL[s1], WD[s1]);
     };
-    using PH0 = std::integral_constant<int, 0>;
-    using PH2 = std::integral_constant<int, 2>;
-    int k = 0;
-    for (; k + 4 <= nr; k += 4) {
-        block(PH0{}, k, rawA, rawB);
-        block(PH2{}, k + 2, rawB, rawA);
-    }
-    bool odd_phase = false;
-    if (k + 2 <= nr) { block(PH0{}, k, rawA, rawB); k += 2; odd_phase = true; }
-    if (k < nr) {                                           // one row left, already in the window
-        if (odd_phase) row_math(WL[2], WL[3], WL[0], WD[2], WD[3], WD[0], k);
-        else row_math(WL[0], WL[1], WL[2], WD[0], WD[1], WD[2], k);
-    }
-    if (HALO >= 2 && !active) { acc_max = 0.f; acc_l = 0.f; acc_d = 0.f; }
-
-    // ---- exact mode: float64 re-evaluation of this wave's queued near-tie cells ----
-    if (EXACT) {
-        if (nq) wait_row_stores_before_patching();              // wave-uniform
-        if (nq <= (unsigned)G.qcap) {
+    // Exact mode: float64 re-evaluation of this wave's queued near-tie cells, one entry per lane - when the strip is
+    // finished and whenever the queue is half full, so that it never overflows on states the dynamics produce (a
+    // strip whose queue did overflow lost entries and is recomputed whole in float64 below: tens of times slower).
+    bool redo = false;
+    const int flush_at = G.qcap >> 1;
+    float fix_max = 0.f, fix_l = 0.f, fix_d = 0.f;          // what the sweeps change in this lane's reductions (their
+                                                            // entries are not the lane's own cells: kept apart from acc_*)
+    auto sweep_queue = [&]() {
+        if (nq > (unsigned)G.qcap) redo = true;
+        if (!redo && nq) {
+            wait_row_stores_before_patching();                  // patches land inside rows this wave stored
+            const PhysF64* p64 = &P64;                          // cold constants: loaded here, not held across the row loop
+            asm volatile("" : "+s"(p64));
+            const PhysF64 Pe = *p64;
             for (unsigned int e = lane; e < nq; e += 64) {
                 const uint4 e0 = q[e * 3], e1 = q[e * 3 + 1], e2 = q[e * 3 + 2];
                 const unsigned int w[9] = {unpack_ld(e0.z), unpack_ld(e0.w), unpack_ld(e1.x),
                                            unpack_ld(e1.y), unpack_ld(e1.z), unpack_ld(e1.w),
                                            unpack_ld(e2.x), unpack_ld(e2.y), unpack_ld(e2.z)};
                 const unsigned int f32v = unpack_ld(e2.w);
-                const NewCoverF64 o = cell_f64_lean(P64, w);
+                const NewCoverF64 o = cell_f64_lean(Pe, w);
                 const float kl = (float)dw_round3_k(o.nl), kd = (float)dw_round3_k(o.nd);
                 const size_t off = (size_t)e0.x * G.H * G.W + (size_t)(e0.y >> 16) * G.W + (e0.y & 0xffffu);
                 outL[off] = (plane_t)kl;                    // after this wave's own row store (see wait_row_stores_before_patching)
@@ -367,13 +354,41 @@ __device__ __forceinline__ void stream_body(const plane_t* __restrict__ inL, con
                     atomicAdd(&stats[e0.x].sum_l, (unsigned long long)(long long)(kl - (float)(f32v & 0xffffu)));
                     atomicAdd(&stats[e0.x].sum_d, (unsigned long long)(long long)(kd - (float)(f32v >> 16)));
                 } else {
-                    acc_l += kl - (float)(f32v & 0xffffu);
-                    acc_d += kd - (float)(f32v >> 16);
-                    acc_max = fmaxf(acc_max, fmaxf(kl, kd));
+                    fix_l += kl - (float)(f32v & 0xffffu);
+                    fix_d += kd - (float)(f32v >> 16);
+                    fix_max = fmaxf(fix_max, fmaxf(kl, kd));
                 }
             }
+            if (lane == 0) atomicAdd(fixups, (unsigned long long)nq);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the queue is reused: reads above before later pushes
+            __builtin_amdgcn_wave_barrier();
+        }
+        nq = 0;
+    };
+    using PH0 = std::integral_constant<int, 0>;
+    using PH2 = std::integral_constant<int, 2>;
+    int k = 0;
+    for (; k + 4 <= nr; k += 4) {
+        block(PH0{}, k, rawA, rawB);
+        block(PH2{}, k + 2, rawB, rawA);
+        if (EXACT && __builtin_expect(nq >= (unsigned)flush_at, 0)) sweep_queue();    // wave-uniform; rare
+    }
+    bool odd_phase = false;
+    if (k + 2 <= nr) { block(PH0{}, k, rawA, rawB); k += 2; odd_phase = true; }
+    if (k < nr) {                                           // one row left, already in the window
+        if (odd_phase) row_math(WL[2], WL[3], WL[0], WD[2], WD[3], WD[0], k);
+        else row_math(WL[0], WL[1], WL[2], WD[0], WD[1], WD[2], k);
+    }
+    if (HALO >= 2 && !active) { acc_max = 0.f; acc_l = 0.f; acc_d = 0.f; }
+
+    // ---- exact mode: the entries of the strip's last rows; a strip that lost entries: whole in float64 ----
+    if (EXACT) {
+        sweep_queue();
+        if (!redo) {
+            acc_l += fix_l;
+            acc_d += fix_d;
+            acc_max = fmaxf(acc_max, fix_max);
         } else {                                            // queue overflow: the whole strip in float64
-            report_overflow(ovf, ovf_seq, lane);
             acc_max = 0.f; acc_l = 0.f; acc_d = 0.f;
             const int nc = PACK ? 256 : min(256, G.W - c0);
             for (int i = lane; i < nr * nc; i += 64) {
@@ -430,7 +445,6 @@ __device__ __forceinline__ void stream_body(const plane_t* __restrict__ inL, con
             atomicAdd(&stats[world].sum_l, (unsigned long long)sl);
             atomicAdd(&stats[world].sum_d, (unsigned long long)sd);
         }
-        if (EXACT && nq && lane == 0) atomicAdd(fixups, (unsigned long long)nq);
     } else {
         const float m = wave_max(acc_max);
         const float sl = wave_sum(acc_l), sd = wave_sum(acc_d);
@@ -438,7 +452,6 @@ __device__ __forceinline__ void stream_body(const plane_t* __restrict__ inL, con
             atomicMax(&stats[b].max_k, (unsigned int)m);
             atomicAdd(&stats[b].sum_l, (unsigned long long)sl);
             atomicAdd(&stats[b].sum_d, (unsigned long long)sd);
-            if (EXACT && nq) atomicAdd(fixups, (unsigned long long)nq);
         }
     }
 
@@ -472,7 +485,6 @@ struct StreamExactArgs {
     const plane_t* inL; const plane_t* inD; plane_t* outL; plane_t* outD;
     StripGeom G; PhysF32 P; StatsDev* stats; unsigned long long* fixups; unsigned long long* zero_me; int zero_n;
     PhysF64 P64;                                                  // cold
-    unsigned int* ovf; unsigned int ovf_seq;                      // cold: where a queue overflow is reported
 };
 
 template <int HALO, bool SYM = false>
@@ -480,7 +492,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DW_STREAM_W
 void step_stream_exact(StreamExactArgs A) {
     const StreamExactArgs& cold = kernarg_struct<StreamExactArgs>();
     stream_body<true, HALO, DW_STREAM_RB_EXACT, SYM>(A.inL, A.inD, A.outL, A.outD, A.G, A.P, cold.P64, A.stats, A.fixups,
-                                                     A.zero_me, A.zero_n, &cold.ovf, &cold.ovf_seq);
+                                                     A.zero_me, A.zero_n);
 }
 
 }  // namespace dw
