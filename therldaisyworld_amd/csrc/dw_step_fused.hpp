@@ -176,9 +176,9 @@ __device__ __forceinline__ void fused2_body(const TI* __restrict__ inL, const TI
         need1[2] = writes;
         need1[3] = writes || wr;
     }
-    // tie flags: lane masks on the scalar unit, except in the STATS and the packed variants (per-lane bools: they are
-    // at their register budget with those and spill inside the row loop otherwise, see dw_step_stream.hpp)
-    constexpr bool LANE_BOOLS = STATS || PACK;
+    // tie flags: lane masks on the scalar unit, except in the packed variants and the STATS variant of the overlapped
+    // strips (per-lane bools: they are at their register budget with those and spill inside the row loop otherwise)
+    constexpr bool LANE_BOOLS = PACK || (STATS && MODE == kFusedOvl);
     using TieT = std::conditional_t<LANE_BOOLS, bool, unsigned long long>;
     TieT need1m[4], writes_m;
     if constexpr (LANE_BOOLS) {
@@ -263,8 +263,18 @@ __device__ __forceinline__ void fused2_body(const TI* __restrict__ inL, const TI
         if constexpr ((PIN & 4) != 0) { asm volatile("" : "+v"(P1.eKb)); P2.eKb = P1.eKb; }
         if constexpr ((PIN & 8) != 0) { asm volatile("" : "+v"(P1.gt)); P2.gt = P1.gt; }
     }
-    float st_m1 = 0.f;                                          // STATS accumulators of this lane
-    unsigned int st_c2 = 0, st_nmm = 0;
+    // STATS accumulators.  Un-packed worlds (CHEAP): st_m1 = this lane's maximum of the float32 step-1 values, ties
+    // included (a near-tie cell's float32 value is within one quantum of the exact one, so a maximum >= thr + 2 proves
+    // the biosphere alive whatever the ties were); st_x1 = exact values that decide otherwise (maximum <= thr + 1: a
+    // dying world) - the float64 value of every queued step-1 cell, and the NON-tie cells of row groups whose maximum
+    // is exactly thr + 1; st_c2w = wave total of output row groups whose float32 step-2 maximum is >= thr + 2 (exact
+    // mode; float32-only mode: > thr).  Packed worlds keep one maximum / count per lane (several worlds per wave).
+    constexpr bool CHEAP = STATS && !PACK;
+    static_assert(LAG || !CHEAP, "the dependent-order loop (DW_FUSED_LAG=0, experiments) keeps the per-lane statistics");
+    float st_m1 = 0.f, st_x1 = 0.f;
+    unsigned int st_c2 = 0, st_nmm = 0, st_c2w = 0;
+    const unsigned long long writes_mask = CHEAP ? lane_mask(writes) : 0ull;
+    const float thr_c2 = EXACT ? thr_hi + 1.0f : thr_hi;
     // one row of the map with coefficient set P: (up, mid, down) -> new values; exact mode also queues
     // the near-tie cells (kind 1 = step 1, 2 = step 2; lrow = row index relative to grid row r0-2)
     auto row_map = [&](const PhysF32& P, const Row4& upL, const Row4& miL, const Row4& dnL, const Row4& upD,
@@ -277,11 +287,15 @@ __device__ __forceinline__ void fused2_body(const TI* __restrict__ inL, const TI
 #pragma unroll
             for (int i = 0; i < 4; ++i) tie[i] = tie[i] & use[i];
         }
-        if (STATS && sure_max) {                                 // max over the cells whose float32 value is certain
-            float m = 0.f;
+        if (STATS && sure_max) {
+            if (CHEAP) {                                         // the row group's float32 maximum (four v_max3)
+                *sure_max = fmaxf(fmaxf(fmaxf(ol[0], ol[1]), fmaxf(ol[2], ol[3])), fmaxf(fmaxf(od[0], od[1]), fmaxf(od[2], od[3])));
+            } else {                                             // max over the cells whose float32 value is certain
+                float m = 0.f;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) m = fmaxf(m, (EXACT && tie_lane(tie[i])) ? 0.f : fmaxf(ol[i], od[i]));
-            *sure_max = m;
+                for (int i = 0; i < 4; ++i) m = fmaxf(m, (EXACT && tie_lane(tie[i])) ? 0.f : fmaxf(ol[i], od[i]));
+                *sure_max = m;
+            }
         }
         nl = make_float4(ol[0], ol[1], ol[2], ol[3]);
         nd = make_float4(od[0], od[1], od[2], od[3]);
@@ -301,11 +315,15 @@ __device__ __forceinline__ void fused2_body(const TI* __restrict__ inL, const TI
 #pragma unroll
             for (int i = 0; i < 4; ++i) tie[i] = tie[i] & use[i];
         }
-        if (STATS && sure_max) {                                 // max over the cells whose float32 value is certain
-            float m = 0.f;
+        if (STATS && sure_max) {
+            if (CHEAP) {                                         // the row group's float32 maximum (four v_max3)
+                *sure_max = fmaxf(fmaxf(fmaxf(ol[0], ol[1]), fmaxf(ol[2], ol[3])), fmaxf(fmaxf(od[0], od[1]), fmaxf(od[2], od[3])));
+            } else {                                             // max over the cells whose float32 value is certain
+                float m = 0.f;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) m = fmaxf(m, (EXACT && tie_lane(tie[i])) ? 0.f : fmaxf(ol[i], od[i]));
-            *sure_max = m;
+                for (int i = 0; i < 4; ++i) m = fmaxf(m, (EXACT && tie_lane(tie[i])) ? 0.f : fmaxf(ol[i], od[i]));
+                *sure_max = m;
+            }
         }
     };
     auto row_queue = [&](const Row4& upL, const Row4& miL, const Row4& dnL, const Row4& upD, const Row4& miD,
@@ -316,6 +334,25 @@ __device__ __forceinline__ void fused2_body(const TI* __restrict__ inL, const TI
             queue_tie<1>(tie[1], nq, q, (unsigned)G.qcap, kind, lrow, 4 * lane, upL, miL, dnL, upD, miD, dnD, ol, od);
             queue_tie<2>(tie[2], nq, q, (unsigned)G.qcap, kind, lrow, 4 * lane, upL, miL, dnL, upD, miD, dnD, ol, od);
             queue_tie<3>(tie[3], nq, q, (unsigned)G.qcap, kind, lrow, 4 * lane, upL, miL, dnL, upD, miD, dnD, ol, od);
+        }
+    };
+    // STATS bookkeeping of one step-2 / step-1 row map (sm = what row_cells / row_map returned through sure_max)
+    auto stats_step2 = [&](float sm) {
+        if (CHEAP) st_c2w += (unsigned int)__popcll(__builtin_amdgcn_fcmpf(sm, thr_c2, 2 /* OGT */) & writes_mask);
+        else if (writes && sm > thr_hi) st_c2 += 1u;
+    };
+    auto stats_step1 = [&](float sm, const float* ol, const float* od, const TieT* tie, bool rows_mine) {
+        if (!rows_mine) return;                                 // wave-uniform: step-1 rows of MY output cells only
+        if (writes) st_m1 = fmaxf(st_m1, sm);
+        if (CHEAP && EXACT) {
+            // a row group whose float32 maximum is exactly thr + 1 decides only through its NON-tie cells (rare)
+            const unsigned long long eq = __builtin_amdgcn_fcmpf(sm, thr_hi + 1.0f, 1 /* OEQ */) & writes_mask;
+            if (__builtin_expect(eq != 0ull, 0)) {
+                float m = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) m = fmaxf(m, tie_lane(tie[i]) ? 0.f : fmaxf(ol[i], od[i]));
+                st_x1 = fmaxf(st_x1, in_mask(eq) ? m : 0.f);
+            }
         }
     };
     const TieT use2[4] = {writes_m, writes_m, writes_m, writes_m};
@@ -387,7 +424,7 @@ __device__ __forceinline__ void fused2_body(const TI* __restrict__ inL, const TI
                         if (STATS && is_output((int)(where >> 16), (int)(where & 0xffffu))) {   // exact value of a tie cell
                             const unsigned int mx = kl > kd ? kl : kd;
                             if (PACK) atomicMax(&pstats[2 * world_of((int)(where & 0xffffu))], mx);   // any world of the row
-                            else st_m1 = fmaxf(st_m1, (float)mx);              // my wave's world: reduced below
+                            else st_x1 = fmaxf(st_x1, (float)mx);              // my wave's world: reduced below
                         }
                     } else {
                         int gr, gc;
@@ -457,7 +494,7 @@ __device__ __forceinline__ void fused2_body(const TI* __restrict__ inL, const TI
             if (do2) {
                 row_queue(SL[u], SL[(u + 1) % 3], SL[(u + 2) % 3], SD[u], SD[(u + 1) % 3], SD[(u + 2) % 3], l2, d2, tie2, 2,
                           j - 2);
-                if (STATS && writes && sm2 > thr_hi) st_c2 += 1u;
+                if (STATS) stats_step2(sm2);
                 if (writes) {
                     const size_t off = woff + (size_t)(r0 + j - 4) * G.W + col;
                     stream_store4(outL + off, make_float4(l2[0], l2[1], l2[2], l2[3]));
@@ -466,7 +503,7 @@ __device__ __forceinline__ void fused2_body(const TI* __restrict__ inL, const TI
             }
             if (do1) {
                 row_queue(IL[(u + 2) % 3], IL[u], IL[(u + 1) % 3], ID[(u + 2) % 3], ID[u], ID[(u + 1) % 3], l1, d1, tie1, 1, j);
-                if (STATS && writes && j >= 2 && j <= nr + 1) st_m1 = fmaxf(st_m1, sm1);   // step-1 rows of MY output cells
+                if (STATS) stats_step1(sm1, l1, d1, tie1, j >= 2 && j <= nr + 1);
                 if constexpr (RING) {                               // both new rows in ONE exchange (one barrier per iteration)
                     const float4 v[4] = {make_float4(l1[0], l1[1], l1[2], l1[3]), make_float4(d1[0], d1[1], d1[2], d1[3]),
                                          widen4(nx.l), widen4(nx.d)};
@@ -635,7 +672,9 @@ __device__ __forceinline__ void fused2_body(const TI* __restrict__ inL, const TI
                 }
             }
             st_m1 = 0.f;
+            st_x1 = 0.f;
             st_c2 = 0;
+            st_c2w = 0;
         }
         st_nmm = nmm;
     }
@@ -664,10 +703,11 @@ __device__ __forceinline__ void fused2_body(const TI* __restrict__ inL, const TI
                 if (c) atomicAdd(&pstats[2 * (b * G.wpr + pw) + 1], c);
             }
         } else {
-            const float m = wave_max(st_m1);
-            unsigned int c = st_c2;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) c += (unsigned int)__shfl_xor((int)c, o, 64);
+            // st_m1 >= thr + 2 somewhere in the strip: alive, whatever the near-ties were; otherwise the exact values
+            // decide (float32-only mode: the float32 values ARE the values)
+            const float mf = wave_max(st_m1), mx = wave_max(st_x1);
+            const float m = (EXACT && !(mf > thr_hi + 1.0f)) ? mx : mf;
+            unsigned int c = st_c2w;                             // already the wave's total
             c = c > 9u * st_nmm ? c - 9u * st_nmm : 0u;
             if (lane == 0) {
                 atomicMax(&pstats[2 * b], (unsigned int)m);

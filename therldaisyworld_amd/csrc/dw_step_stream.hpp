@@ -38,6 +38,11 @@ namespace dw {
 #ifndef DW_STREAM_WAVES_EXACT
 #define DW_STREAM_WAVES_EXACT 3
 #endif
+// (1: the exact kernel evaluates the cells of both rows of a block before reductions, stores and pushes - 3 % fewer
+// instructions, but measured 4.7 % SLOWER on C2 and 1 % faster on 64 x 4096^2: off)
+#ifndef DW_STREAM_EXACT_PAIRED
+#define DW_STREAM_EXACT_PAIRED 0
+#endif
 
 struct StripGeom {
     int B, H, W;
@@ -195,10 +200,21 @@ __device__ __forceinline__ void queue_tie(F tie, unsigned int& n, uint4* __restr
 template <bool EXACT, int HALO, int RB, bool SYM = false>
 __device__ __forceinline__ void stream_body(const plane_t* __restrict__ inL, const plane_t* __restrict__ inD,
                                             plane_t* __restrict__ outL, plane_t* __restrict__ outD, const StripGeom& G,
-                                            const PhysF32& P, const PhysF64& P64, StatsDev* __restrict__ stats,
+                                            const PhysF32& P_, const PhysF64& P64, StatsDev* __restrict__ stats,
                                             unsigned long long* __restrict__ fixups,
                                             unsigned long long* __restrict__ zero_me, int zero_n) {
     __shared__ uint4 s_queue[EXACT ? 4 * kWaveQueueCap * 3 : 1];
+    // exact kernels: the addend constants of fmas whose multiplier is a scalar pair too, held in VGPRs for the whole
+    // strip (see the fused kernels' PIN; bit mask: 2 pck, 4 eKb, 8 gt)
+#ifndef DW_STREAM_PIN
+#define DW_STREAM_PIN 0
+#endif
+    PhysF32 P = P_;
+    if constexpr (EXACT && DW_STREAM_PIN != 0) {
+        if constexpr ((DW_STREAM_PIN & 2) != 0) asm volatile("" : "+v"(P.pck));
+        if constexpr ((DW_STREAM_PIN & 4) != 0) asm volatile("" : "+v"(P.eKb));
+        if constexpr ((DW_STREAM_PIN & 8) != 0) asm volatile("" : "+v"(P.gt));
+    }
     const int bid = blockIdx.x;
     const int wg = (bid & 7) * G.chunk + (bid >> 3);            // XCD-aware: contiguous run per XCD
     if (wg >= G.nwg) return;
@@ -234,6 +250,7 @@ __device__ __forceinline__ void stream_body(const plane_t* __restrict__ inL, con
     const plane_t* pD = inD + woff;
     const int last_row = r0 + nr;                           // one past the strip: the bottom halo row
     float acc_max = 0.f, acc_l = 0.f, acc_d = 0.f;
+    dw_f32x2 accp_l = dw_f32x2(0.f), accp_d = dw_f32x2(0.f);  // the row loop sums cell PAIRS (one packed add for two cells)
     unsigned int nq = 0;                                    // entries queued by this wave (uniform)
 
     auto load_raw = [&](int rr) -> Raw {                    // rr in [r0-1, r0+nr], clamped + wrapped
@@ -277,8 +294,9 @@ __device__ __forceinline__ void stream_body(const plane_t* __restrict__ inL, con
             } else {
                 acc_max = fmaxf(acc_max, fmaxf(ol[i], od[i]));
             }
-            acc_l += ol[i]; acc_d += od[i];
         }
+        accp_l += dw_f32x2{ol[0], ol[1]} + dw_f32x2{ol[2], ol[3]};      // integers < 2^24: exact in any order
+        accp_d += dw_f32x2{od[0], od[1]} + dw_f32x2{od[2], od[3]};
         if (HALO < 2 || active) {                           // HALO 0/1: every lane owns real columns
             const size_t off = woff + (size_t)(r0 + k) * G.W + colq;
             stream_store4(outL + off, make_float4(ol[0], ol[1], ol[2], ol[3]));
@@ -318,8 +336,44 @@ __device__ __forceinline__ void stream_body(const plane_t* __restrict__ inL, con
             use[1] = load_raw(r0 + kk + 4);
         }
         __builtin_amdgcn_sched_barrier(0);                  // loads first, then the arithmetic
-        row_math(WL[s0], WL[s1], WL[s2], WD[s0], WD[s1], WD[s2], kk);
-        row_math(WL[s1], WL[s2], WL[s3], WD[s1], WD[s2], WD[s3], kk + 1);
+        if constexpr (EXACT && DW_STREAM_EXACT_PAIRED != 0) {
+            // the cells of BOTH rows first - two independent row maps in one basic block, their transcendental chains
+            // overlap - then reductions, stores and, behind ONE wave-uniform test, the queue pushes of both rows
+            float olA[4], odA[4], olB[4], odB[4];
+            unsigned long long tieA[4], tieB[4];
+            cells4<EXACT, SYM, unsigned long long>(P, WL[s0], WL[s1], WL[s2], WD[s0], WD[s1], WD[s2], olA, odA, tieA);
+            cells4<EXACT, SYM, unsigned long long>(P, WL[s1], WL[s2], WL[s3], WD[s1], WD[s2], WD[s3], olB, odB, tieB);
+            unsigned long long any = 0ull;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (HALO >= 2) { tieA[i] &= active_mask; tieB[i] &= active_mask; }
+                acc_max = fmaxf(acc_max, in_mask(tieA[i]) ? 0.f : fmaxf(olA[i], odA[i]));
+                acc_max = fmaxf(acc_max, in_mask(tieB[i]) ? 0.f : fmaxf(olB[i], odB[i]));
+                any |= tieA[i] | tieB[i];
+            }
+            accp_l += (dw_f32x2{olA[0], olA[1]} + dw_f32x2{olA[2], olA[3]}) + (dw_f32x2{olB[0], olB[1]} + dw_f32x2{olB[2], olB[3]});
+            accp_d += (dw_f32x2{odA[0], odA[1]} + dw_f32x2{odA[2], odA[3]}) + (dw_f32x2{odB[0], odB[1]} + dw_f32x2{odB[2], odB[3]});
+            if (HALO < 2 || active) {
+                const size_t off = woff + (size_t)(r0 + kk) * G.W + colq;
+                stream_store4(outL + off, make_float4(olA[0], olA[1], olA[2], olA[3]));
+                stream_store4(outD + off, make_float4(odA[0], odA[1], odA[2], odA[3]));
+                stream_store4(outL + off + G.W, make_float4(olB[0], olB[1], olB[2], olB[3]));
+                stream_store4(outD + off + G.W, make_float4(odB[0], odB[1], odB[2], odB[3]));
+            }
+            if (any != 0ull) {
+                queue_tie<0>(tieA[0], nq, q, (unsigned)G.qcap, world, r0 + kk, colq, WL[s0], WL[s1], WL[s2], WD[s0], WD[s1], WD[s2], olA, odA);
+                queue_tie<1>(tieA[1], nq, q, (unsigned)G.qcap, world, r0 + kk, colq, WL[s0], WL[s1], WL[s2], WD[s0], WD[s1], WD[s2], olA, odA);
+                queue_tie<2>(tieA[2], nq, q, (unsigned)G.qcap, world, r0 + kk, colq, WL[s0], WL[s1], WL[s2], WD[s0], WD[s1], WD[s2], olA, odA);
+                queue_tie<3>(tieA[3], nq, q, (unsigned)G.qcap, world, r0 + kk, colq, WL[s0], WL[s1], WL[s2], WD[s0], WD[s1], WD[s2], olA, odA);
+                queue_tie<0>(tieB[0], nq, q, (unsigned)G.qcap, world, r0 + kk + 1, colq, WL[s1], WL[s2], WL[s3], WD[s1], WD[s2], WD[s3], olB, odB);
+                queue_tie<1>(tieB[1], nq, q, (unsigned)G.qcap, world, r0 + kk + 1, colq, WL[s1], WL[s2], WL[s3], WD[s1], WD[s2], WD[s3], olB, odB);
+                queue_tie<2>(tieB[2], nq, q, (unsigned)G.qcap, world, r0 + kk + 1, colq, WL[s1], WL[s2], WL[s3], WD[s1], WD[s2], WD[s3], olB, odB);
+                queue_tie<3>(tieB[3], nq, q, (unsigned)G.qcap, world, r0 + kk + 1, colq, WL[s1], WL[s2], WL[s3], WD[s1], WD[s2], WD[s3], olB, odB);
+            }
+        } else {
+            row_math(WL[s0], WL[s1], WL[s2], WD[s0], WD[s1], WD[s2], kk);
+            row_math(WL[s1], WL[s2], WL[s3], WD[s1], WD[s2], WD[s3], kk + 1);
+        }
         __builtin_amdgcn_sched_barrier(0);
         to_rows(use[0], WL[s0], WD[s0]);                    // rows kk+3, kk+4: window rows 2, 3 of the next block
         to_rows(use[1], WL[s1], WD[s1]);
@@ -379,6 +433,8 @@ __device__ __forceinline__ void stream_body(const plane_t* __restrict__ inL, con
         if (odd_phase) row_math(WL[2], WL[3], WL[0], WD[2], WD[3], WD[0], k);
         else row_math(WL[0], WL[1], WL[2], WD[0], WD[1], WD[2], k);
     }
+    acc_l = accp_l.x + accp_l.y;
+    acc_d = accp_d.x + accp_d.y;
     if (HALO >= 2 && !active) { acc_max = 0.f; acc_l = 0.f; acc_d = 0.f; }
 
     // ---- exact mode: the entries of the strip's last rows; a strip that lost entries: whole in float64 ----
