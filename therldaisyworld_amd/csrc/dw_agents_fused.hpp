@@ -64,6 +64,10 @@ struct LookaheadArgs {
     int* idx; double* st;                        // agents after step t, updated to step t+1
     const signed char* code;                     // [B][N] for step t+1: 0..8 action, -1 greedy argmax, -2 argmin
     unsigned char* agent_ok;                     // [B][N] reward >= 0.1 after step t+1, or null
+    // step t+2's policy + update_agents too (phase E), when the chunk continues: the next pair then starts with its
+    // fused launch (two launches per pair instead of four).  Null: the caller runs them as kernels of their own.
+    const signed char* code_next;                // [B][N] for step t+2, or null
+    unsigned char* agent_ok_next;                // [B][N] reward >= 0.1 after step t+2's update_agents
     // per-step "biosphere alive" flags (max cover > thr/1000) of the two steps, or null; pstats[2b], [2b+1]:
     // the fused launch's exact step-1 maximum and its count of certain step-2 row groups above thr
     unsigned char* alive_t; unsigned char* alive_t1;
@@ -177,9 +181,12 @@ __global__ __launch_bounds__(64) void agents_lookahead_patch(LookaheadArgs A) {
         const int an = b * N + lane;
         const double s = s_st[lane];
         const double cl = s < 0.0 ? 0.0 : (s > 1.0 ? 1.0 : s);
-        A.st[an] = cl;
-        A.idx[(size_t)an * 2] = s_ar[lane];
-        A.idx[(size_t)an * 2 + 1] = s_ac[lane];
+        s_st[lane] = cl;                                          // phase E starts from the clipped stores
+        if (!A.code_next) {                                       // (phase E writes the agents back itself)
+            A.st[an] = cl;
+            A.idx[(size_t)an * 2] = s_ar[lane];
+            A.idx[(size_t)an * 2 + 1] = s_ac[lane];
+        }
         if (A.agent_ok) A.agent_ok[an] = (cl * (cl > 0.0 ? 1.0 : 0.0)) < 0.1 ? 0 : 1;
     }
 
@@ -235,6 +242,90 @@ __global__ __launch_bounds__(64) void agents_lookahead_patch(LookaheadArgs A) {
             for (int i = lane; i < H * W; i += 64) m = fmaxf(m, fmaxf((float)oL[woff + i], (float)oD[woff + i]));
             m = wave_max(m);
             if (lane == 0) A.alive_t1[b] = m > (float)A.thr ? 1 : 0;
+        }
+    }
+
+    // ---- E: step t+2's policy and update_agents on the patched S2 (ref Greedy :18-30, update_agents :181-244) ----
+    if (A.code_next) {
+        __threadfence_block();
+        __syncthreads();                                          // this block's patch stores before its loads of S2
+        {
+            const int dr[5] = {0, 0, -1, 1, 0}, dc[5] = {0, -1, 0, 0, 1};
+            for (int t = lane; t < N * 5; t += 64) {
+                const int n = t / 5, i = t - n * 5;
+                const int r = ((s_ar[n] + dr[i]) % H + H) % H, c = ((s_ac[n] + dc[i]) % W + W) % W;
+                const size_t off = woff + (size_t)r * W + c;
+                // (volatile: past this CU's vector cache, which may hold the line from before the patch)
+                const TO l = __builtin_bit_cast(TO, *reinterpret_cast<const volatile unsigned short*>(oL + off));
+                const TO d = __builtin_bit_cast(TO, *reinterpret_cast<const volatile unsigned short*>(oD + off));
+                s_s1[n][i] = (unsigned int)(float)l | ((unsigned int)(float)d << 16);
+            }
+        }
+        __syncthreads();
+        if (lane < N) {
+            const int an = b * N + lane;
+            int a = (int)A.code_next[an];
+            if (a < 0) {
+                const bool argmin = a == -2;
+                const int cand[4] = {3, 1, 7, 5};
+                int best = 0;
+                double bestv = 0.0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const unsigned int w = s_s1[lane][i + 1];
+                    double val = 0.0;
+                    if ((A.mask >> cand[i]) & 1)
+                        val = (double)(float)(w & 0xffffu) / 1000.0 + (double)(float)(w >> 16) / 1000.0;
+                    if (i == 0 || (argmin ? val < bestv : val > bestv)) { best = i; bestv = val; }
+                }
+                a = 4 + best;
+            }
+            s_act[lane] = a;
+        }
+        __syncthreads();
+        if (lane == 0) {
+            for (int n = 0; n < N; ++n) s_st[n] -= A.agent_gamma;
+            int ng2 = 0;
+            for (int n = 0; n < N; ++n) {
+                double s = s_st[n];
+                if (s > 0.0) {
+                    const int a = s_act[n];
+                    int r = s_ar[n], c = s_ac[n];
+                    int which = 0;
+                    if (a != 8) {
+                        const int m = ((a % 4) + 4) % 4;
+                        if (m == 0) { c -= 1; which = 1; } else if (m == 1) { r -= 1; which = 2; }
+                        else if (m == 2) { r += 1; which = 3; } else { c += 1; which = 4; }
+                    }
+                    r = ((r % H) + H) % H;
+                    c = ((c % W) + W) % W;
+                    s_ar[n] = r;
+                    s_ac[n] = c;
+                    if (a > 4) {
+                        bool eaten = false;                   // an earlier agent of this step emptied the cell
+                        for (int g = 0; g < ng2; ++g) eaten = eaten || (s_gr[g] == r && s_gc[g] == c);
+                        if (!eaten) {
+                            const unsigned int w = s_s1[n][which];
+                            s += (double)(float)(w & 0xffffu) / 1000.0 + (double)(float)(w >> 16) / 1000.0;
+                            s_gr[ng2] = r; s_gc[ng2] = c; ++ng2;
+                            const size_t off = woff + (size_t)r * W + c;
+                            oL[off] = (TO)0.f;                // the grazed cell (ref :214-216)
+                            oD[off] = (TO)0.f;
+                        }
+                        s_st[n] = s;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (lane < N) {
+            const int an = b * N + lane;
+            const double s = s_st[lane];
+            const double cl = s < 0.0 ? 0.0 : (s > 1.0 ? 1.0 : s);
+            A.st[an] = cl;
+            A.idx[(size_t)an * 2] = s_ar[lane];
+            A.idx[(size_t)an * 2 + 1] = s_ac[lane];
+            if (A.agent_ok_next) A.agent_ok_next[an] = (cl * (cl > 0.0 ? 1.0 : 0.0)) < 0.1 ? 0 : 1;
         }
     }
 }

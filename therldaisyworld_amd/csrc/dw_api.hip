@@ -1876,9 +1876,15 @@ static int run_episode_stepwise(dw_handle* h, int32_t nsteps, const double* L_sc
     if (may_pair && policy_mode != DW_POLICY_TABLE)
         HIPCHK(hipMemsetAsync(h->ep_buf + o_code, uniform_code, bn, h->stream));
     auto greedy = [&](int argmin, int codes) { return launch_policy_greedy(h, argmin, nullptr, codes); };
+    // policy + update_agents of the step after a pair run inside that pair's patch kernel (phase E) while the chunk
+    // continues: two launches per pair instead of four (DW_NO_AGENT_PREAPPLY: experiments)
+    static const bool no_preapply = std::getenv("DW_NO_AGENT_PREAPPLY") != nullptr;
+    bool pre_applied = false;
     for (size_t t = 0; t < K; ++t) {
         const bool pair = may_pair && cur_quantised(h) && K - t >= 3;
-        if (bn && policy_mode != kPolicySkipAgents) {
+        if (pre_applied) {
+            pre_applied = false;                             // step t's policy and grazing were done by the last patch
+        } else if (bn && policy_mode != kPolicySkipAgents) {
             const bool from_table = policy_mode == DW_POLICY_TABLE || (use_table && use_table[t]);
             if (from_table) {
                 hipLaunchKernelGGL(actions_from_table, dim3((unsigned)((bn + 255) / 256)), dim3(256), 0, h->stream,
@@ -1907,6 +1913,14 @@ static int run_episode_stepwise(dw_handle* h, int32_t nsteps, const double* L_sc
             A.idx = h->idx; A.st = h->st;
             A.code = reinterpret_cast<const signed char*>(codes);
             A.agent_ok = h->ep_buf + o_ok + (t + 1) * bn;
+            A.code_next = nullptr;
+            A.agent_ok_next = nullptr;
+            if (t + 2 < K && !no_preapply) {                   // the chunk continues with step t+2
+                const bool tab3 = policy_mode == DW_POLICY_TABLE || (use_table && use_table[t + 2]);
+                A.code_next = reinterpret_cast<const signed char*>(tab3 ? h->ep_buf + o_tab + (t + 2) * bn : h->ep_buf + o_code);
+                A.agent_ok_next = h->ep_buf + o_ok + (t + 2) * bn;
+                pre_applied = true;
+            }
             A.alive_t = pstats ? h->ep_buf + o_wa + t * B : nullptr;
             A.alive_t1 = pstats ? h->ep_buf + o_wa + (t + 1) * B : nullptr;
             A.pstats = pstats; A.thr = threshold_k;
