@@ -183,3 +183,26 @@ def test_first_exact_step_dense_unquantised_state(amd):
         gl, gd = eng.download_planes()
         assert np.array_equal(_k(gl), _k(ref[:, 1])) and np.array_equal(_k(gd), _k(ref[:, 2])), L
         eng.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# lifespan harness without snapshots / replay (sweeps that discard the environment)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dim,B", [(8, 64), (256, 6)])
+def test_lifespans_only_harness_gives_the_same_lifespans(amd, dim, B):
+    """simulate_lifespan(final_state=False) takes no snapshots and does not replay the chunk in which the last
+    biosphere dies: identical lifespans (they are counted only up to the step the reference loop stops at); the
+    environment is left at the end of that chunk."""
+    from therldaisyworld_amd.harness import simulate_lifespan
+    out = []
+    for final_state in (True, False):
+        for make in (lambda: amd.Greedy(epsilon=0.0), lambda: amd.Greedy(epsilon=0.5), lambda: None):
+            np.random.seed(13)
+            env = amd.RLDaisyWorld(grid_dimension=dim, n_agents=4)
+            env.batch_size = B
+            done_at, agents_done_at = simulate_lifespan(env, make(), final_state=final_state)
+            out.append((done_at.copy(), agents_done_at.copy(), env.step_count))
+            env.close()
+    for (d0, a0, s0), (d1, a1, s1) in zip(out[:3], out[3:]):
+        assert np.array_equal(d0, d1) and np.array_equal(a0, a1)
+        assert s0 <= s1 < s0 + 32

@@ -2178,7 +2178,7 @@ int dw_audit_tie_bound(dw_handle* h, double L, double out[4]) {
     HIPCHK(hipMemsetAsync(d, 0, 4 * sizeof(unsigned long long), h->stream));
     const dim3 g((unsigned)((p.height * p.width + 255) / 256), (unsigned)p.batch);
     hipLaunchKernelGGL(tie_audit, g, dim3(256), 0, h->stream, h->L16[h->cur], h->D16[h->cur], p.height, p.width,
-                       derive_f32(p, L), make_f64(p, L), d);
+                       derive_f32(p, L), make_f64(p, L), d, h->sym_albedo && h->use_stream ? 1 : 0);
     HIPCHK(hipGetLastError());
     unsigned long long r[4];
     HIPCHK(hipMemcpyAsync(r, d, sizeof(r), hipMemcpyDeviceToHost, h->stream));

@@ -226,7 +226,7 @@ template <> struct Lanes<float> {
     // the same comparison as the wave's 64-bit lane mask (v_cmp writes exactly that into a scalar pair): the hot
     // kernels combine, test and count tie flags on the scalar unit, with no per-lane booleans in between
     static __device__ __forceinline__ void gtm(float a, float b, unsigned long long* out) {
-        out[0] = __builtin_amdgcn_fcmpf(a, b, 2 /* FCMP_OGT */);
+        out[0] = __builtin_amdgcn_fcmpf(a, b, 10 /* FCMP_UGT: a NaN is a near-tie too (float64 decides) */);
     }
     static __device__ __forceinline__ float load(const float* a, int i) { return a[i]; }
     static __device__ __forceinline__ float fma_abs(float a, float b, float c) { return __builtin_fmaf(a, __builtin_fabsf(b), c); }
@@ -247,8 +247,8 @@ template <> struct Lanes<dw_f32x2> {
     static __device__ __forceinline__ float get(T v, int i) { return i == 0 ? v.x : v.y; }
     static __device__ __forceinline__ void gt(T a, T b, bool* out) { out[0] = a.x > b.x; out[1] = a.y > b.y; }
     static __device__ __forceinline__ void gtm(T a, T b, unsigned long long* out) {
-        out[0] = __builtin_amdgcn_fcmpf(a.x, b.x, 2 /* FCMP_OGT */);
-        out[1] = __builtin_amdgcn_fcmpf(a.y, b.y, 2);
+        out[0] = __builtin_amdgcn_fcmpf(a.x, b.x, 10 /* FCMP_UGT */);
+        out[1] = __builtin_amdgcn_fcmpf(a.y, b.y, 10);
     }
     static __device__ __forceinline__ T load(const float* a, int i) { return T{a[i], a[i + 1]}; }
     // a*|b| + c per lane with the scalar VOP3 fma: its |.| source modifier is free, packed ops have none

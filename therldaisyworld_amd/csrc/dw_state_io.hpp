@@ -89,8 +89,9 @@ __global__ void agents_stamp(double* __restrict__ grid7, const int* __restrict__
 //   out[2] = number of cells the tie test flags   out[3] = number of cells audited
 // (both species count).  Non-negative doubles order like their bit patterns: atomicMax on u64.
 // ---------------------------------------------------------------------------------------------
+// `sym`: audit the two-term coefficient chain the exact wave-strip kernels use for symmetric albedos (growth_t<.., SYM>)
 __global__ __launch_bounds__(256) void tie_audit(const plane_t* __restrict__ L, const plane_t* __restrict__ D, int H, int W,
-                                                 PhysF32 P, PhysF64 P64, unsigned long long* __restrict__ out) {
+                                                 PhysF32 P, PhysF64 P64, unsigned long long* __restrict__ out, int sym) {
     const int b = blockIdx.y;
     const int cell = blockIdx.x * 256 + threadIdx.x;
     if (cell >= H * W) return;
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(256) void tie_audit(const plane_t* __restrict__ L, 
     const float Ed = (DW_AT(pd, ru, c) + DW_AT(pd, rd, c)) + (DW_AT(pd, r, cl) + DW_AT(pd, r, cr));
     const float Cd = (DW_AT(pd, ru, cl) + DW_AT(pd, rd, cl)) + (DW_AT(pd, ru, cr) + DW_AT(pd, rd, cr));
 #undef DW_AT
-    const GrowthF32 g = growth_f32<true>(P, li, di, El, Cl, Ed, Cd);
+    const GrowthF32 g = sym ? growth_f32<true, true>(P, li, di, El, Cl, Ed, Cd) : growth_f32<true, false>(P, li, di, El, Cl, Ed, Cd);
     double l9[9], d9[9];
     gather9(pl, H, W, r, c, l9);
     gather9(pd, H, W, r, c, d9);

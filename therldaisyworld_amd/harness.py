@@ -72,10 +72,16 @@ def _luminosity_schedule(env, nsteps):
     return out
 
 
-def simulate_lifespan(env, agent, chunk=32, use_device_loop=True, obs=None):
+def simulate_lifespan(env, agent, chunk=32, use_device_loop=True, obs=None, final_state=True):
     """`obs=None`: reset the environment first, as the notebook's harness does.  Pass the observations of
     a reset the caller has already done (e.g. `env.reset_synthetic(seed); obs = env.get_obs()` — the
-    device-side initial state for ensembles too large to draw from the host's legacy RNG)."""
+    device-side initial state for ensembles too large to draw from the host's legacy RNG).
+
+    `final_state=False`: the caller wants the lifespans only (a sweep that discards the environment).  The chunk in
+    which the last biosphere dies is then NOT replayed from a snapshot for exactly the remaining steps, and no
+    snapshots are taken: the lifespans are the same numbers, but the environment (grid, agents, L, step_count, and the
+    legacy-RNG stream when the policy draws) is left at the END of that chunk, up to `chunk - 1` steps past the point
+    the reference loop stops at."""
     if obs is None:
         obs = env.reset()
     B, N = obs.shape[0], obs.shape[1]
@@ -107,13 +113,16 @@ def simulate_lifespan(env, agent, chunk=32, use_device_loop=True, obs=None):
                 table[t] = agent.draw_random_actions(B, N)[..., 0]
             rng_after.append(np.random.get_state())
         Ls = _luminosity_schedule(env, K)
-        eng.snapshot_save()
+        if final_state:
+            eng.snapshot_save()
         alive_k, ok_k = eng.run_episode(Ls, mode, use_table, table, LIFESPAN_THRESHOLD_K)
         all_dead = ~alive_k.any(axis=1)
         executed = int(np.argmax(all_dead)) + 1 if all_dead.any() else K
         done_at += alive_k[:executed].sum(axis=0)
         agents_done_at += ok_k[:executed].sum(axis=0)[..., None]
-        if executed < K:
+        if not final_state:
+            executed = K                                       # the environment stays where the chunk ended
+        elif executed < K:
             # the episode ended inside the chunk: replay exactly `executed` steps from the snapshot
             eng.snapshot_restore()
             eng.run_episode(Ls[:executed], mode, use_table[:executed], table[:executed], LIFESPAN_THRESHOLD_K)

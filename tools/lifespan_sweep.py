@@ -70,6 +70,9 @@ def main():
                          "device-side initial state with the same distribution (reset_synthetic)")
     ap.add_argument("--albedos", default="default", choices=["default", "neutral"],
                     help="neutral: albedo_light = albedo_dark = 0.5 (the notebook's control case)")
+    ap.add_argument("--lifespans-only", action="store_true",
+                    help="simulate_lifespan(final_state=False): no snapshots, the last chunk is not replayed - the same "
+                         "lifespans, the environments are discarded anyway")
     ap.add_argument("--gpus", type=int, default=0,
                     help="start this many ranks (one per GPU) and supervise them; 0: run as the single process / the "
                          "torchrun rank this process already is")
@@ -119,7 +122,7 @@ def main():
         else:
             obs = env.reset()
         t_reset = time.perf_counter() - t0
-        done_at, agents_done_at = simulate_lifespan(env, make(), obs=obs)
+        done_at, agents_done_at = simulate_lifespan(env, make(), obs=obs, final_state=not args.lifespans_only)
         wall = time.perf_counter() - t0
         steps = env.step_count
         env.close()
