@@ -38,8 +38,8 @@
  * the mathematically identical 9-tap stencil, and the float64 repair path forms T_x^4 directly instead
  * of through the chain of fourth roots - both differ from the reference by a few 1e-16 relative BEFORE
  * rounding, the size of the reference's own FFT noise; a cell whose float64 pre-rounding value lies
- * that close to a rounding tie could round differently (never observed: 1.4e10 cell-updates soaked
- * against the oracle, 0 mismatches); (ii) un-quantised outputs - reset() observations, env.grid after
+ * that close to a rounding tie could round differently (never observed: 2e10 cell-updates soaked
+ * against the oracle on the round-3 kernels alone, 0 mismatches); (ii) un-quantised outputs - reset() observations, env.grid after
  * reset(), the temp / beta / growth caches - agree with the reference to ~1e-13 relative, not bit for bit.
  */
 #ifndef DAISYWORLD_HIP_H
@@ -77,7 +77,8 @@ enum {
      * is amplified by the dynamics): that is what the exact mode is for. */
     DW_PRECISION_FAST = 1,
     /* float64 arithmetic for every cell (slow; the in-library reference the other two are tested
-     * against, and the path used for the first step from an un-quantised initial state). */
+     * against).  (The exact mode's first step from an un-quantised initial state is float32 with an error bound
+     * for non-integer inputs, float64 only for the cells that bound cannot decide: the same results.) */
     DW_PRECISION_F64 = 2
 };
 
@@ -151,8 +152,10 @@ const char* dw_build_id(void);
 /* ---- state in / out ------------------------------------------------------------------------- */
 
 /* Upload an initial cover state, cover fractions in natural units [B][H][W] float64; the state is
- * treated as NOT quantised (ref initialize_grid :285-324 does not round), so the next step is
- * evaluated in float64 from these exact values.  Resets the retained "previous" state. */
+ * treated as NOT quantised (ref initialize_grid :285-324 does not round): it is kept as uploaded, and the
+ * next step reads these exact values (exact mode: float32 with a bound for non-integer inputs, the undecided
+ * cells in float64 from the originals - bit-identical to a float64 evaluation).  Resets the retained
+ * "previous" state. */
 int dw_upload_state_f64(dw_handle* h, const double* light, const double* dark);
 
 /* Same from float32 natural-unit planes.  quantised != 0 asserts every value is k/1000 (it is rounded to the
