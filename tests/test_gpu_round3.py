@@ -128,7 +128,7 @@ def test_tall_strips_do_not_overflow_any_more(amd, monkeypatch):
     ms64, p64 = run({})
     ms128, p128 = run({"DW_STRIP_ROWS": "128"})
     assert np.array_equal(_k(p64[0]), _k(p128[0])) and np.array_equal(_k(p64[1]), _k(p128[1]))
-    assert ms128 <= 1.25 * ms64, (ms64, ms128)                   # (not faster: fewer, longer strips; measured 1.14x)
+    assert ms128 <= 1.4 * ms64, (ms64, ms128)                    # (round 2: 4x; not faster: fewer, longer strips - measured 1.14x)
 
 
 # ---------------------------------------------------------------------------------------------
