@@ -135,12 +135,13 @@ def test_tall_strips_do_not_overflow_any_more(amd, monkeypatch):
 # the first exact step from an un-quantised state is float32 + a tie bound, float64 for flagged cells only
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("fmt", ["f64", "f32", "philox"])
-@pytest.mark.parametrize("shape", [(3, 200, 260), (2, 512, 512), (5, 64, 64)])
+@pytest.mark.parametrize("shape", [(3, 200, 260), (2, 512, 512), (5, 64, 64), (3, 100, 1024), (70, 7, 256)])
 def test_first_exact_step_from_unquantised_state_is_bit_exact(amd, fmt, shape):
     """The reference's initial grid is not rounded (ref :285-324): the first step reads float64 natural covers (or,
     for the synthetic ensembles, float32 per-mille ones).  It now runs in float32 with the error bound for
     non-integer inputs and re-evaluates only the flagged cells in float64: results identical to the float64
-    oracle on the same state, for all three upload formats, several luminosities, and a small flagged fraction."""
+    oracle on the same state, for all three upload formats, several luminosities, and a small flagged fraction.
+    Widths that are multiples of 256 take the wave-strip kernel (step_first_stream), the others step_generic."""
     from oracle import c_oracle
     B, H, W = shape
     rng = np.random.RandomState(B * H + W)
@@ -184,6 +185,50 @@ def test_first_exact_step_dense_unquantised_state(amd):
         gl, gd = eng.download_planes()
         assert np.array_equal(_k(gl), _k(ref[:, 1])) and np.array_equal(_k(gd), _k(ref[:, 2])), L
         eng.close()
+
+
+@pytest.mark.parametrize("fmt", ["f64", "f32"])
+@pytest.mark.parametrize("shape", [(2, 256, 256), (2, 130, 768)])
+def test_first_step_kernels_agree_and_the_flag_list_sweeps(amd, monkeypatch, fmt, shape):
+    """The wave-strip first-step kernel against the one-thread-per-cell kernel (DW_FIRST_GENERIC=1) on the same
+    un-rounded state: float32-only mode bit-identical (the same operations in the same order); exact mode identical
+    to the float64 oracle also when a widened bracket (DW_TEST_FIRST_SLACK) flags a large share of the cells, so
+    that every wave sweeps its list of flagged cells several times inside its strip."""
+    from oracle import c_oracle
+    B, H, W = shape
+    rng = np.random.RandomState(H + W)
+    light = rng.rand(B, H, W) * (rng.rand(B, H, W) > 0.4)
+    dark = rng.rand(B, H, W) * (rng.rand(B, H, W) > 0.4)
+
+    def first(precision, env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        eng = _engine(amd, B, H, W, 0, precision)
+        if fmt == "f64":
+            eng.upload_state(light, dark)
+        else:
+            eng.upload_state_f32(light.astype(np.float32), dark.astype(np.float32), quantised=False)
+        state = eng.download_planes()
+        eng.step(1.1)
+        for k in env:
+            monkeypatch.delenv(k)
+        out = eng.download_planes()
+        fix = eng.last_fixup_count()
+        s = eng.reduce()
+        eng.close()
+        return state, out, fix, s
+
+    _, a, _, sa = first("fast", {})
+    _, g, _, sg = first("fast", {"DW_FIRST_GENERIC": "1"})
+    assert np.array_equal(_k(a[0]), _k(g[0])) and np.array_equal(_k(a[1]), _k(g[1]))
+    assert np.array_equal(sa["sum_light_k"], sg["sum_light_k"]) and np.array_equal(sa["max_k"], sg["max_k"])
+    state, e, fix, se = first("exact", {"DW_TEST_FIRST_SLACK": "0.1"})
+    ref = c_oracle.forward(state[0], state[1], 1.1)
+    assert np.array_equal(_k(e[0]), _k(ref[:, 1])) and np.array_equal(_k(e[1]), _k(ref[:, 2]))
+    assert fix > 0.1 * B * H * W                                  # (a strip of 256 x 64 cells lists > 1600: >= 6 sweeps)
+    assert np.array_equal(se["sum_light_k"], _k(e[0]).sum(axis=(1, 2)).astype(np.uint64))
+    assert np.array_equal(se["sum_dark_k"], _k(e[1]).sum(axis=(1, 2)).astype(np.uint64))
+    assert np.array_equal(se["max_k"], np.maximum(_k(e[0]).max(axis=(1, 2)), _k(e[1]).max(axis=(1, 2))).astype(np.uint32))
 
 
 # ---------------------------------------------------------------------------------------------

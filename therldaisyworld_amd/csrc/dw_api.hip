@@ -450,6 +450,10 @@ static FirstStepBound derive_first_bound(const dw_params& p, double L, const Phy
     B.eA = up(safety * ((kK + 3.0 * u) + u + (kK + u)));
     B.cS = up(safety * u);                                        // the sum k + gq rounds (u |sum|); a float64 k was rounded (u k)
     B.slack = admissible ? 4e-6f : 1.0f;                          // the float32 arithmetic of eps itself; inadmissible: all float64
+    if (const char* e = std::getenv("DW_TEST_FIRST_SLACK")) {    // tests: a wider bracket flags many cells (list sweeps)
+        const float v = (float)std::atof(e);
+        if (v > B.slack) B.slack = v;
+    }
     return B;
 }
 
@@ -639,7 +643,35 @@ static int launch_forward(dw_handle* h, double L) {
 #define DW_GEN3(T, IL, ID, FB)                                                                                    \
     hipLaunchKernelGGL((step_generic<T, 3>), ggrid, dim3(256), 0, h->stream, IL, ID, h->L16[out], h->D16[out],    \
                        p.height, p.width, P, P64, stats, fixups, zero_me, zero_n, gcpt, FB)
-        if (h->unq_kind == UNQ_F64) {
+        // widths that are multiples of 256: the wave-strip form of the same arithmetic (dw_step_first.hpp; ~4x fewer
+        // vector instructions per cell).  DW_FIRST_GENERIC=1: the one-thread-per-cell kernel (experiments, tests)
+        const bool first_stream = p.width % 256 == 0 && (f32arith || bounded) && !std::getenv("DW_FIRST_GENERIC");
+        if (first_stream) {
+            FirstGeom fg;
+            fg.B = p.batch; fg.H = p.height; fg.W = p.width;
+            fg.ncs = p.width / 256;
+            int sr = 64;                                         // shorter strips until every SIMD has four
+            while (sr > 8 && (long)p.batch * fg.ncs * ((p.height + sr - 1) / sr) < 4096) sr >>= 1;
+            fg.SR = p.height < sr ? p.height : sr;
+            fg.nrs = (p.height + fg.SR - 1) / fg.SR;
+            fg.nstrips = p.batch * fg.nrs * fg.ncs;
+            const dim3 fgrid((unsigned)((fg.nstrips + 3) / 4));
+            const FirstStepBound fb = bounded ? derive_first_bound(p, L, P, h->unq_kind == UNQ_F64) : FirstStepBound{};
+#define DW_FIRST(T, PR, HL, IL, ID)                                                                               \
+    hipLaunchKernelGGL((step_first_stream<T, PR, HL>), fgrid, dim3(256), 0, h->stream, IL, ID, h->L16[out],       \
+                       h->D16[out], fg, P, P64, stats, fixups, zero_me, zero_n, fb)
+#define DW_FIRST_HL(T, PR, IL, ID)                                                                                \
+    do { if (fg.ncs == 1) DW_FIRST(T, PR, 0, IL, ID); else DW_FIRST(T, PR, 1, IL, ID); } while (0)
+            if (h->unq_kind == UNQ_F64) {
+                if (f32arith) DW_FIRST_HL(double, 1, h->L64, h->D64);
+                else DW_FIRST_HL(double, 3, h->L64, h->D64);
+            } else {
+                if (f32arith) DW_FIRST_HL(float, 1, h->U32L, h->U32D);
+                else DW_FIRST_HL(float, 3, h->U32L, h->U32D);
+            }
+#undef DW_FIRST_HL
+#undef DW_FIRST
+        } else if (h->unq_kind == UNQ_F64) {
             if (f32arith) DW_GEN(double, 1, h->L64, h->D64);
             else if (bounded) DW_GEN3(double, h->L64, h->D64, derive_first_bound(p, L, P, true));
             else DW_GEN(double, 2, h->L64, h->D64);

@@ -6,6 +6,7 @@
 //   dw_step_tiled.hpp     step_tiled        LDS tile + halo (W < 256), global near-tie queues, fix-up kernels
 //   dw_step_stream.hpp    step_stream_*     wave-strip streaming kernel (W >= 256): the single-step hot kernel
 //   dw_step_fused.hpp     step_stream_fused2[_exact]   two steps per HBM round trip (dw_step_n): the headline
+//   dw_step_first.hpp     step_first_stream  the first step of an episode (un-quantised input), W a multiple of 256
 //   dw_episode.hpp        episode_small     K steps in one launch with the worlds in LDS (H*W <= 4096)
 //   dw_agents.hpp         agents_update (ref :181-244), observe (ref get_obs :246-263), policy_greedy
 //                         (agents/greedy.py:14-36), policy_mlp (agents/mlp.py:97-116), reward/done, lifespans
@@ -21,6 +22,7 @@
 #include "dw_step_tiled.hpp"
 #include "dw_step_stream.hpp"
 #include "dw_step_fused.hpp"
+#include "dw_step_first.hpp"
 #include "dw_episode.hpp"
 #include "dw_agents.hpp"
 #include "dw_state_io.hpp"

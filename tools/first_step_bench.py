@@ -10,7 +10,7 @@ from therldaisyworld_amd import _ffi  # noqa: E402
 
 args = [int(x) for x in sys.argv[1:]] or [1024, 256]
 for B, G in zip(args[0::2], args[1::2]):
-    for prec, env in (("exact", {}), ("fast", {})):
+    for prec, env in (("exact", {}), ("fast", {}), ("exact", {"DW_FIRST_GENERIC": "1"}), ("fast", {"DW_FIRST_GENERIC": "1"})):
         os.environ.update(env)
         p = amd.default_params(B, G, G, 0)
         p.precision = _ffi.PRECISION[prec]
@@ -24,7 +24,7 @@ for B, G in zip(args[0::2], args[1::2]):
             times.append(eng.timer_stop())
         fix = eng.last_fixup_count()
         eng.close()
-        for k in env:
+        for k in env:                                            # (read by the library at every launch)
             os.environ.pop(k)
-        print(f"{B} x {G}^2 {prec:5s} {'all-f64' if env else '':8s} first step: {min(times):9.3f} ms (min of 3), "
+        print(f"{B} x {G}^2 {prec:5s} {'one thread per cell' if env else 'default':19s} first step: {min(times):9.3f} ms (min of 3), "
               f"float64 cells {fix} = {100.0 * fix / (B * G * G):.4f} %", flush=True)
