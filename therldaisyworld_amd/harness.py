@@ -136,9 +136,10 @@ def simulate_lifespan(env, agent, chunk=32, use_device_loop=True, obs=None, fina
     # the worker costs ~0.2 ms per chunk)
     pool = ThreadPoolExecutor(max_workers=1) if agent is not None and getattr(agent, "epsilon", 1.0) > 0.0 else None
     try:
-        ahead = draw_chunk()
+        ahead = None
         while True:
-            rng_before, use_table, table = ahead
+            rng_before, use_table, table = ahead if ahead is not None else draw_chunk()
+            ahead = None
             Ls = _luminosity_schedule(env, K)
 
             def on_device():
