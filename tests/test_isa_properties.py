@@ -116,3 +116,18 @@ def test_fused_float32_kernels_instruction_budget(asm):
         assert len(trans) == 144, (name, len(trans))        # 24 cell-evaluations x 6
         assert len(valu) <= 33 * 24, (name, len(valu))
         assert not any(ln.startswith("\tv_mov_b32_dpp") for ln in loop), name
+
+
+def test_first_step_stream_kernels_are_packed_and_spill_free(asm):
+    """step_first_stream (the first step of an episode on widths that are multiples of 256): packed float32 in its row
+    loop, no scratch anywhere in the kernel, float32-only variants at >= 4 waves/SIMD, the bounded exact ones at >= 3."""
+    ks = {n: v for n, v in _kernels(asm).items() if "step_first_stream" in n}
+    assert len(ks) == 8                                       # float / double input x float32-only / bounded x HALO 0 / 1
+    for name, (info, body) in ks.items():
+        assert not re.search(r"\tscratch_", body), name
+        bounded = "Li3E" in name
+        assert info["Occupancy"] >= (3 if bounded else 4), (name, info["NumVgprs"])
+        loop = _hot_loop(body)
+        npk = sum(1 for ln in loop if ln.startswith("\tv_pk_"))
+        ntr = sum(1 for ln in loop if re.match(r"\tv_(sqrt|rcp)_f32", ln))
+        assert npk >= 40 and ntr == (32 if bounded else 24), (name, npk, ntr)   # 4 cells x (6 + the bound's two roots)
