@@ -540,6 +540,7 @@ static void select_kernel(dw_handle* h) {
         f.ncs = packable ? 1 : (p.width + f.cols_per_strip - 1) / f.cols_per_strip;
         f.qcap = g.qcap;
         f.mcap = mcap;
+        f.sure_need = 9 * p.n_agents + 9 * mcap + 1;            // (dw_step_fused.hpp, STATS)
         set_strip_rows(h, g.SR);
         return;
     }

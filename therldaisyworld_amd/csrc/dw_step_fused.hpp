@@ -33,6 +33,8 @@ struct FusedGeom {
     int cols_per_strip;       // 256 (ROT) or 248 (OVL)
     int qcap, mcap;           // queue / mismatch-list capacities in use (tests shrink them)
     int lpw, wpr;             // packed mode (W < 256): lanes per world row (W/4), worlds per wave row (64 / lpw)
+    int sure_need;            // STATS: sure step-2 row groups after which a wave's count cannot matter any more:
+                              // 9 per agent (patched cells) + 9 per possible step-1 mismatch (deducted) + 1
 };
 
 // float64 step-1 value of grid cell (r, c) (any integers: wrapped onto the torus) from the input planes,
@@ -273,6 +275,12 @@ __device__ __forceinline__ void fused2_body(const TI* __restrict__ inL, const TI
     static_assert(LAG || !CHEAP, "the dependent-order loop (DW_FUSED_LAG=0, experiments) keeps the per-lane statistics");
     float st_m1 = 0.f, st_x1 = 0.f;
     unsigned int st_c2 = 0, st_nmm = 0, st_c2w = 0;
+    // CHEAP: both results are only ever read as predicates by agents_lookahead_patch - "some step-1 value > thr" and
+    // "more sure step-2 row groups than the patches can touch" (9 per grazed cell, 9 per step-1 mismatch deducted
+    // below).  Once a wave holds a CERTAIN step-1 value >= thr + 2 and G.sure_need sure step-2 groups, nothing it could
+    // still add changes either predicate: the rest of the strip runs in a copy of the row loop without the statistics
+    // (a living world with 4 agents: after ~12 of its 64 rows; G.sure_need, host).  st_sure1: wave-uniform.
+    bool st_sure1 = false;
     const unsigned long long writes_mask = CHEAP ? lane_mask(writes) : 0ull;
     const float thr_c2 = EXACT ? thr_hi + 1.0f : thr_hi;
     // one row of the map with coefficient set P: (up, mid, down) -> new values; exact mode also queues
@@ -344,6 +352,7 @@ __device__ __forceinline__ void fused2_body(const TI* __restrict__ inL, const TI
     auto stats_step1 = [&](float sm, const float* ol, const float* od, const TieT* tie, bool rows_mine) {
         if (!rows_mine) return;                                 // wave-uniform: step-1 rows of MY output cells only
         if (writes) st_m1 = fmaxf(st_m1, sm);
+        if (CHEAP) st_sure1 = st_sure1 || (__builtin_amdgcn_fcmpf(sm, thr_hi + 1.0f, 2 /* OGT */) & writes_mask) != 0ull;
         if (CHEAP && EXACT) {
             // a row group whose float32 maximum is exactly thr + 1 decides only through its NON-tie cells (rare)
             const unsigned long long eq = __builtin_amdgcn_fcmpf(sm, thr_hi + 1.0f, 1 /* OEQ */) & writes_mask;
@@ -476,9 +485,10 @@ __device__ __forceinline__ void fused2_body(const TI* __restrict__ inL, const TI
         // which are all results of EARLIER iterations: the two row maps of an iteration are independent, so
         // their transcendental chains overlap instead of waiting for each other.  Step-1 row j then replaces
         // step-1 row j-3 in the window.
-        auto iter = [&](auto U, auto D1, auto D2, int j) {
+        auto iter = [&](auto U, auto D1, auto D2, int j, auto ST) {
             constexpr int u = decltype(U)::value;                  // u == j % 3
             constexpr bool do1 = decltype(D1)::value, do2 = decltype(D2)::value;
+            constexpr bool st_on = STATS && decltype(ST)::value;   // (the quiet copy of the loop: statistics off)
             RawIn nx;
             if (do1) nx = load_raw(r0 + j);                        // input row j+2, needed by the NEXT iteration
             __builtin_amdgcn_sched_barrier(0);
@@ -487,14 +497,14 @@ __device__ __forceinline__ void fused2_body(const TI* __restrict__ inL, const TI
             float sm1 = 0.f, sm2 = 0.f;
             if (do2)
                 row_cells(P2, SL[u], SL[(u + 1) % 3], SL[(u + 2) % 3], SD[u], SD[(u + 1) % 3], SD[(u + 2) % 3], l2, d2, tie2,
-                          use2, STATS ? &sm2 : nullptr);
+                          use2, st_on ? &sm2 : nullptr);
             if (do1)
                 row_cells(P1, IL[(u + 2) % 3], IL[u], IL[(u + 1) % 3], ID[(u + 2) % 3], ID[u], ID[(u + 1) % 3], l1, d1, tie1,
-                          need1m, STATS ? &sm1 : nullptr);
+                          need1m, st_on ? &sm1 : nullptr);
             if (do2) {
                 row_queue(SL[u], SL[(u + 1) % 3], SL[(u + 2) % 3], SD[u], SD[(u + 1) % 3], SD[(u + 2) % 3], l2, d2, tie2, 2,
                           j - 2);
-                if (STATS) stats_step2(sm2);
+                if (st_on) stats_step2(sm2);
                 if (writes) {
                     const size_t off = woff + (size_t)(r0 + j - 4) * G.W + col;
                     stream_store4(outL + off, make_float4(l2[0], l2[1], l2[2], l2[3]));
@@ -503,7 +513,7 @@ __device__ __forceinline__ void fused2_body(const TI* __restrict__ inL, const TI
             }
             if (do1) {
                 row_queue(IL[(u + 2) % 3], IL[u], IL[(u + 1) % 3], ID[(u + 2) % 3], ID[u], ID[(u + 1) % 3], l1, d1, tie1, 1, j);
-                if (STATS) stats_step1(sm1, l1, d1, tie1, j >= 2 && j <= nr + 1);
+                if (st_on) stats_step1(sm1, l1, d1, tie1, j >= 2 && j <= nr + 1);
                 if constexpr (RING) {                               // both new rows in ONE exchange (one barrier per iteration)
                     const float4 v[4] = {make_float4(l1[0], l1[1], l1[2], l1[3]), make_float4(d1[0], d1[1], d1[2], d1[3]),
                                          widen4(nx.l), widen4(nx.d)};
@@ -519,25 +529,35 @@ __device__ __forceinline__ void fused2_body(const TI* __restrict__ inL, const TI
         };
         using Yes = std::true_type;
         using No = std::false_type;
-        iter(U1{}, Yes{}, No{}, 1);                                // nr >= 1: rows 1..3 always exist
-        iter(U2{}, Yes{}, No{}, 2);
-        iter(U0{}, Yes{}, No{}, 3);
+        iter(U1{}, Yes{}, No{}, 1, Yes{});                          // nr >= 1: rows 1..3 always exist
+        iter(U2{}, Yes{}, No{}, 2, Yes{});
+        iter(U0{}, Yes{}, No{}, 3, Yes{});
         const int jend = nr + 2;
         int j = 4;
         for (; j + 2 <= jend; j += 3) {                             // j % 3 == 1 at the top
-            iter(U1{}, Yes{}, Yes{}, j);
-            iter(U2{}, Yes{}, Yes{}, j + 1);
-            iter(U0{}, Yes{}, Yes{}, j + 2);
+            iter(U1{}, Yes{}, Yes{}, j, Yes{});
+            iter(U2{}, Yes{}, Yes{}, j + 1, Yes{});
+            iter(U0{}, Yes{}, Yes{}, j + 2, Yes{});
             // wave-uniform and rare (see sweep_queue); not in the STATS variants, which are at their register budget: their
             // live values would spill on the main path (they keep one sweep at the end of the strip)
             if (EXACT && !STATS && __builtin_expect(nq >= (unsigned)flush_at, 0)) sweep_queue();
+            if (CHEAP && st_sure1 && st_c2w >= (unsigned int)G.sure_need) { j += 3; break; }   // both predicates are decided: see st_sure1
         }
-        if (j <= jend) { iter(U1{}, Yes{}, Yes{}, j); ++j; }
-        if (j <= jend) { iter(U2{}, Yes{}, Yes{}, j); ++j; }
+        if constexpr (CHEAP) {
+            // the rest of the strip with the statistics switched off: a second copy of the row loop rather than a
+            // branch around the statistics in the first (that one costs the exact kernels registers they do not have)
+            for (; j + 2 <= jend; j += 3) {
+                iter(U1{}, Yes{}, Yes{}, j, No{});
+                iter(U2{}, Yes{}, Yes{}, j + 1, No{});
+                iter(U0{}, Yes{}, Yes{}, j + 2, No{});
+            }
+        }
+        if (j <= jend) { iter(U1{}, Yes{}, Yes{}, j, Yes{}); ++j; }   // (the last rows: statistics on again - they only grow)
+        if (j <= jend) { iter(U2{}, Yes{}, Yes{}, j, Yes{}); ++j; }
         // j == nr + 3: the last output row
-        if (j % 3 == 1) iter(U1{}, No{}, Yes{}, j);
-        else if (j % 3 == 2) iter(U2{}, No{}, Yes{}, j);
-        else iter(U0{}, No{}, Yes{}, j);
+        if (j % 3 == 1) iter(U1{}, No{}, Yes{}, j, Yes{});
+        else if (j % 3 == 2) iter(U2{}, No{}, Yes{}, j, Yes{});
+        else iter(U0{}, No{}, Yes{}, j, Yes{});
     } else {
         // iteration j = 1 .. nr+2: step-1 row j (grid row r0-2+j) from input rows j-1, j, j+1; then, from j = 3
         // on, output row k = j-3 (local row j-1) from step-1 rows j-2, j-1, j
