@@ -15,7 +15,7 @@ the per-world lifespans are gathered once (RCCL all-gather of a few kB) and rank
 The step loop is device-resident in chunks (`dw_run_episode`): one launch per chunk for dim*dim <= 4096,
 back-to-back launches without host round trips for larger worlds.  Measured on one MI355X, 1000 worlds,
 4 agents, run to the death of every biosphere: dim 8: 0.015-0.1 s per policy; dim 256 (the C4 shard):
-0.076-0.083 s per policy exact, 0.058-0.065 s with --precision fast (~468 steps, step pairs in one fused
+0.074-0.083 s per policy exact (0.068-0.078 with --lifespans-only), 0.056-0.065 s with --precision fast (~468 steps, step pairs in one fused
 launch with the agents' step patched in) plus 1.0 s for the reference-compatible host-RNG reset
 (`--init philox` draws the initial state on the device instead: 3 ms).
 """
