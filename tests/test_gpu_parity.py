@@ -591,6 +591,33 @@ def test_lifespan_harness_random_configurations_vs_notebook_loop_on_oracle(amd, 
     assert ok, log
 
 
+@pytest.mark.parametrize("seed,case", [(603, 26), (603, 3), (601, 17), (602, 44), (605, 120), (607, 9)])
+def test_exact_mode_random_configurations_vs_c_oracle(amd, monkeypatch, seed, case):
+    """A slice of tools/fuzz_exact.py: random shape / constants / upload format / luminosity schedule, planes AND
+    reductions against the float64 C oracle.  (603, 26) is the case that found a round-3 regression: packed strips
+    (W = 128) with the repair queue cut to one entry - a strip swept its queue inside the row loop, sent the sweep's
+    sum corrections to the world's counters, overflowed later, was recomputed whole and counted those corrections
+    twice (sum of light cover off by one); the corrections of packed strips now wait in LDS until the strip is known
+    to finish without an overflow."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_exact.py")
+    spec = importlib.util.spec_from_file_location("fuzz_exact", path)
+    mod = importlib.util.module_from_spec(spec)
+    saved = os.environ.get("DW_PACK_MIN_STRIPS")
+    try:
+        spec.loader.exec_module(mod)                     # (sets DW_PACK_MIN_STRIPS=1 if unset, like the fixture above)
+        log = []
+        same, ratio = mod.run_case(seed, case, log)
+    finally:
+        if saved is None:
+            os.environ.pop("DW_PACK_MIN_STRIPS", None)
+        else:
+            os.environ["DW_PACK_MIN_STRIPS"] = saved
+    assert same, log
+    assert ratio < 0.6, log                              # the proven bound is never approached (DESIGN.md 3.5)
+
+
 @pytest.mark.default_pack_threshold
 @pytest.mark.parametrize("seed", list(range(70000, 70012)))
 def test_engine_random_call_sequences_vs_oracle_model(amd, seed):

@@ -252,6 +252,17 @@ __device__ __forceinline__ void stream_body(const plane_t* __restrict__ inL, con
     float acc_max = 0.f, acc_l = 0.f, acc_d = 0.f;
     dw_f32x2 accp_l = dw_f32x2(0.f), accp_d = dw_f32x2(0.f);  // the row loop sums cell PAIRS (one packed add for two cells)
     unsigned int nq = 0;                                    // entries queued by this wave (uniform)
+    // packed exact strips: what the queue sweeps change in the SUMS of the wave row's worlds (an entry's world is not
+    // the sweeping lane's), per wave in LDS: [world of the wave row][light, dark] (wpr <= 32).  They reach the global
+    // counters only when the strip is finished WITHOUT an overflow - a strip that loses entries after an earlier sweep
+    // is recomputed whole and adds every cell's full value, so corrections already sent there would count twice.
+    __shared__ int s_pfix[(EXACT && PACK) ? 4 * 64 : 1];
+    int* const pfix = s_pfix + ((EXACT && PACK) ? wv * 64 : 0);
+    if (EXACT && PACK) {
+        pfix[lane] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
 
     auto load_raw = [&](int rr) -> Raw {                    // rr in [r0-1, r0+nr], clamped + wrapped
         rr = min(rr, last_row);
@@ -403,10 +414,12 @@ __device__ __forceinline__ void stream_body(const plane_t* __restrict__ inL, con
                 const size_t off = (size_t)e0.x * G.H * G.W + (size_t)(e0.y >> 16) * G.W + (e0.y & 0xffffu);
                 outL[off] = (plane_t)kl;                    // after this wave's own row store (see wait_row_stores_before_patching)
                 outD[off] = (plane_t)kd;
-                if (PACK) {                                 // the entry's world is not this lane's: straight to its counters
-                    atomicMax(&stats[e0.x].max_k, (unsigned int)fmaxf(kl, kd));
-                    atomicAdd(&stats[e0.x].sum_l, (unsigned long long)(long long)(kl - (float)(f32v & 0xffffu)));
-                    atomicAdd(&stats[e0.x].sum_d, (unsigned long long)(long long)(kd - (float)(f32v >> 16)));
+                if (PACK) {                                 // the entry's world is not this lane's
+                    atomicMax(&stats[e0.x].max_k, (unsigned int)fmaxf(kl, kd));   // an exact final value: right in any case
+                    const int pwe = (int)e0.x - b * G.wpr;
+                    const int dl = (int)(kl - (float)(f32v & 0xffffu)), dd = (int)(kd - (float)(f32v >> 16));
+                    if (dl) atomicAdd(&pfix[2 * pwe], dl);
+                    if (dd) atomicAdd(&pfix[2 * pwe + 1], dd);
                 } else {
                     fix_l += kl - (float)(f32v & 0xffffu);
                     fix_d += kd - (float)(f32v >> 16);
@@ -444,6 +457,15 @@ __device__ __forceinline__ void stream_body(const plane_t* __restrict__ inL, con
             acc_l += fix_l;
             acc_d += fix_d;
             acc_max = fmaxf(acc_max, fix_max);
+            if (PACK) {                                     // the sweeps' corrections of the wave row's worlds
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (lane < G.wpr && b * G.wpr + lane < G.B) {
+                    const int dl = pfix[2 * lane], dd = pfix[2 * lane + 1];
+                    if (dl) atomicAdd(&stats[b * G.wpr + lane].sum_l, (unsigned long long)(long long)dl);
+                    if (dd) atomicAdd(&stats[b * G.wpr + lane].sum_d, (unsigned long long)(long long)dd);
+                }
+            }
         } else {                                            // queue overflow: the whole strip in float64
             acc_max = 0.f; acc_l = 0.f; acc_d = 0.f;
             const int nc = PACK ? 256 : min(256, G.W - c0);
