@@ -76,7 +76,7 @@ def check(eng, m, what, log, seed, quantised):
     return not bad
 
 
-def run_case(seed, log):
+def _run_case(seed, log):
     rng = np.random.RandomState(seed)
     dim = int(rng.choice([16, 32, 64, 96, 256, 260, 320]))
     B = int(rng.randint(1, 7 if dim <= 96 else 3))
@@ -178,6 +178,27 @@ def run_case(seed, log):
     info = f"dim={dim} B={B} N={N} pack_min={os.environ.get('DW_PACK_MIN_STRIPS')} ops={len(ops)} :: {eng.kernel_info()[:34]}"
     eng.close()
     return ok, info
+
+
+def run_case(seed, log):
+    """_run_case under a randomly shrunk repair queue / mismatch list in a third of the cases (a side generator: the
+    case itself is unchanged): the exact mode's overflow fallbacks must give the same results."""
+    crng = np.random.RandomState((int(seed) * 2654435761 + 12345) % (2 ** 32))
+    caps = {}
+    if crng.rand() < 0.33:
+        caps = {"DW_TEST_QUEUE_CAP": str(int(crng.choice([1, 4, 16]))), "DW_TEST_MISMATCH_CAP": str(int(crng.choice([0, 1, 2])))}
+    saved = {k: os.environ.pop(k, None) for k in ("DW_TEST_QUEUE_CAP", "DW_TEST_MISMATCH_CAP")}
+    os.environ.update(caps)                              # (read by the library whenever a handle is created)
+    try:
+        out = _run_case(seed, log)
+    finally:
+        for k, v in saved.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
+    if caps and log:
+        log[-1] = f"{log[-1]} {caps}"
+    return out
 
 
 if __name__ == "__main__":

@@ -17,7 +17,7 @@ from therldaisyworld_amd.harness import simulate_lifespan  # noqa: E402
 from oracle import daisy_oracle as O  # noqa: E402
 
 
-def run_case(seed, log):
+def _run_case(seed, log):
     rng = np.random.RandomState(seed)
     dim = int(rng.choice([8, 12, 16, 32, 64, 72, 128, 256]))
     N = int(rng.randint(1, 5))
@@ -61,6 +61,27 @@ def run_case(seed, log):
     if bad:
         log.append(f"seed {seed}: {info}: differs in {bad}")
     return not bad, info
+
+
+def run_case(seed, log):
+    """_run_case under a randomly shrunk repair queue / mismatch list in a third of the cases (a side generator: the
+    case itself is unchanged): the exact mode's overflow fallbacks must give the same results."""
+    crng = np.random.RandomState((int(seed) * 2654435761 + 12345) % (2 ** 32))
+    caps = {}
+    if crng.rand() < 0.33:
+        caps = {"DW_TEST_QUEUE_CAP": str(int(crng.choice([1, 4, 16]))), "DW_TEST_MISMATCH_CAP": str(int(crng.choice([0, 1, 2])))}
+    saved = {k: os.environ.pop(k, None) for k in ("DW_TEST_QUEUE_CAP", "DW_TEST_MISMATCH_CAP")}
+    os.environ.update(caps)                              # (read by the library whenever a handle is created)
+    try:
+        out = _run_case(seed, log)
+    finally:
+        for k, v in saved.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
+    if caps and log:
+        log[-1] = f"{log[-1]} {caps}"
+    return out
 
 
 if __name__ == "__main__":

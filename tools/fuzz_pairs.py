@@ -30,7 +30,18 @@ def run_case(case_seed):
     p = amd.default_params(B, H, W, N)
     p.precision = _ffi.PRECISION[prec]
     p.agent_gamma = float(rng.choice([0.05, 0.2]))           # some agents starve inside the run
-    eng = amd.Engine(p)
+    caps = {}
+    if rng.rand() < 0.3:                                     # shrunk repair queue / mismatch list: the overflow fallbacks
+        caps = {"DW_TEST_QUEUE_CAP": str(int(rng.choice([1, 4, 16]))), "DW_TEST_MISMATCH_CAP": str(int(rng.choice([0, 1, 2])))}
+    saved = {k: os.environ.pop(k, None) for k in ("DW_TEST_QUEUE_CAP", "DW_TEST_MISMATCH_CAP")}
+    os.environ.update(caps)
+    try:
+        eng = amd.Engine(p)                                  # (the library reads them at handle creation)
+    finally:
+        for k, v in saved.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
     eng.init_random(case_seed)
     eng.step(L0, np.zeros((B, N, 1), dtype=int))
     Ls = [min(max(L0 + dL * (i + 1), 0.6), 2.2) for i in range(K)]
@@ -39,7 +50,7 @@ def run_case(case_seed):
            eng.get_obs()]
     if flags:
         out.append(alive)
-    info = f"B={B} H={H} W={W} N={N} {prec} K={K} mode={mode} flags={flags} :: {eng.kernel_info()[:40]}"
+    info = f"B={B} H={H} W={W} N={N} {prec} K={K} mode={mode} flags={flags} {caps} :: {eng.kernel_info()[:40]}"
     eng.close()
     return info, out
 
