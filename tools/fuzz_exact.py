@@ -47,7 +47,12 @@ def run_case(seed, i, log=None, explain=False):
     caps = {}
     if rng.rand() < 0.2:                                # shrink the LDS queue / mismatch list: overflow fallbacks
         caps = {"DW_TEST_QUEUE_CAP": str(int(rng.choice([1, 4, 16]))), "DW_TEST_MISMATCH_CAP": str(int(rng.choice([0, 1, 2])))}
+    # a side generator (the case itself stays what it was): a third of the cases keep the library's own kernel selection,
+    # i.e. small batches of narrow worlds take the tiled / generic kernels instead of the packed wave-strips
+    if np.random.RandomState((seed * 7919 + i * 104729 + 1) % (2 ** 32)).rand() < 0.33:
+        caps = dict(caps, DW_PACK_MIN_STRIPS="512")
     saved = {k: os.environ.pop(k, None) for k in ("DW_TEST_QUEUE_CAP", "DW_TEST_MISMATCH_CAP")}
+    saved["DW_PACK_MIN_STRIPS"] = os.environ.get("DW_PACK_MIN_STRIPS")
     os.environ.update(caps)
     try:
         for k, v in over.items():
