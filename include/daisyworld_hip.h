@@ -248,8 +248,9 @@ int dw_forward_f64(dw_handle* h, const double* light, const double* dark, double
 
 /* One 3x3 toroidal convolution of a caller-supplied float64 plane [B][H][W] with the 9 row-major kernel weights -
  * exactly the operation of ft_convolve (ref daisy/nn/functional.py:12-49, a true convolution on the torus) that
- * calculate_albedo (ref :377-394) and calculate_daisy_density (ref :423-432) are built from; the drop-in's
- * stand-alone calculate_* methods call it.  Does not touch the handle's state. */
+ * calculate_albedo (ref :377-394) and calculate_daisy_density (ref :423-432) are built from.  The drop-in's module-level
+ * therldaisyworld_amd.nn.functional.ft_convolve(grid, kernel) calls it (the calculate_* methods use dw_stage_f64, the step
+ * kernels fuse their stencils).  Does not touch the handle's state. */
 int dw_conv3x3_f64(dw_handle* h, const double* plane, const double kernel[9], double* out);
 
 /* The stages of forward() as stand-alone float64 maps on caller data, evaluated on the device (the drop-in's

@@ -528,6 +528,7 @@ static void select_kernel(dw_handle* h) {
             const int v = std::atoi(e);
             if (v >= 0 && v < kMismatchCap) mcap = v;
         }
+        g.force_rescan = std::getenv("DW_TEST_FORCE_RESCAN") ? 1 : 0;   // tests: the strip maximum's re-scan path
         h->allow_fuse = !std::getenv("DW_NO_FUSE");
         FusedGeom& f = h->fgeom;
         f.B = p.batch; f.H = p.height; f.W = p.width;
@@ -2000,9 +2001,11 @@ static int run_episode_impl(dw_handle* h, int32_t nsteps, const double* L_schedu
     if (C > 4096 || std::getenv("DW_NO_EPISODE_KERNEL"))
         return run_episode_stepwise(h, nsteps, L_schedule, policy_mode, use_table, table, threshold_k, world_alive,
                                     agent_ok);
+    // H*W <= 256 (the README sweep's 8x8, the ES trainers' 16x16): one wave per world (dw_episode_wave.hpp)
+    const bool wave_kernel = C <= kEwMaxCells && N <= 64 && !std::getenv("DW_NO_EPISODE_WAVE");
     const int wpb = C <= 256 ? 4 : (C <= 1024 ? 2 : 1);
-    const size_t world_bytes = episode_world_bytes(C, N);
-    const size_t lds = world_bytes * wpb;
+    const size_t world_bytes = wave_kernel ? episode_wave_world_bytes(C, N) : episode_world_bytes(C, N);
+    const size_t lds = world_bytes * wpb + (wave_kernel ? episode_wave_shared_bytes() : 0);
     NEED(lds <= 160 * 1024, DW_EINVAL, "too many agents for the LDS-resident episode kernel");
     // device staging: [P32 K][Ls K][use_table K][table K*B*N][world_alive K*B][agent_ok K*B*N]
     const size_t K = (size_t)nsteps, bn = (size_t)B * N;
@@ -2036,10 +2039,19 @@ static int run_episode_impl(dw_handle* h, int32_t nsteps, const double* L_schedu
     const PhysF64 P64 = make_f64(p, L_schedule[0]);
     const dim3 grid((unsigned)((B + wpb - 1) / wpb));
     const bool ex = p.precision == DW_PRECISION_EXACT;
-    auto kern = ex ? episode_small<true> : episode_small<false>;
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, h->stream, io, B, N, p.height, p.width, wpb, nsteps, policy_mode,
-                       p.obs_mask, p.agent_gamma, threshold_k, P64);
+    if (wave_kernel) {
+        io.use_table = use_table ? h->ep_buf + o_ut : nullptr;
+        io.table = (table && bn) ? io.table : nullptr;
+        auto kern = ex ? episode_wave<true> : episode_wave<false>;
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, h->stream, io, B, N, p.height, p.width, nsteps, policy_mode,
+                           p.obs_mask, p.agent_gamma, threshold_k, P64);
+    } else {
+        auto kern = ex ? episode_small<true> : episode_small<false>;
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, h->stream, io, B, N, p.height, p.width, wpb, nsteps, policy_mode,
+                           p.obs_mask, p.agent_gamma, threshold_k, P64);
+    }
     HIPCHK(hipGetLastError());
     if (world_alive) HIPCHK(hipMemcpyAsync(world_alive, h->ep_buf + o_wa, K * B, hipMemcpyDeviceToHost, h->stream));
     if (agent_ok && bn) HIPCHK(hipMemcpyAsync(agent_ok, h->ep_buf + o_ok, K * bn, hipMemcpyDeviceToHost, h->stream));

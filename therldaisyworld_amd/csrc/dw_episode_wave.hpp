@@ -1,0 +1,293 @@
+// dw_episode_wave.hpp — episode_wave: the device-resident episode loop for the SMALLEST worlds (H*W <= 256: the README
+// sweep's 8x8 grids, the ES trainers' 16x16), one WAVE per world.
+#pragma once
+#include "dw_episode.hpp"
+
+namespace dw {
+
+// ---------------------------------------------------------------------------------------------
+// episode_wave — round 4.  Same contract as episode_small (EpisodeIO; SURVEY.md 8(f) row N1: policy -> update_agents ->
+// forward -> flags for K steps in one launch; ref notebooks/greedy_longevity_abatement.ipynb cell 2:28-57,
+// daisy/agents/greedy.py:14-36, daisy_world_rl.py:181-244, :434-461), rebuilt around ONE WAVE = ONE WORLD:
+//
+//  * a 64-cell world is exactly one wave, a 256-cell world four cells per lane.  The four waves of a workgroup carry
+//    four INDEPENDENT worlds, so nothing in the step loop is a workgroup barrier (episode_small crossed six per step,
+//    each coupling four unrelated worlds); a wave's own LDS traffic is ordered by program order.
+//  * the step is a chain of dependent latencies - 1000 worlds are 1000 waves on 1024 SIMDs: nothing hides them - so
+//    every global access is taken out of it: the luminosity-dependent constants of up to 64 steps (P32[t], Ls[t],
+//    use_table[t]) and the wave's slice of the host-drawn action table are copied into LDS once per 64-step segment
+//    (the only workgroup barrier), the per-step flags are collected in registers (world: a 64-bit scalar mask over
+//    the segment's steps; agents: one mask per agent lane) and written once per segment.
+//  * agents are lanes, not a serial loop on lane 0: lane n holds agent n's state (float64, the reference's own
+//    operations) and position in registers for the whole launch.  Moving is independent per agent; "the first to land
+//    on a cell eats it all" (ref :186-216) is resolved with N wave-uniform v_readlane pairs - agent n gains the cell's
+//    cover unless an earlier grazing agent landed on the same cell - then every grazed cell is zeroed.
+//  * planes in LDS as interleaved (light, dark) float pairs: one ds_read_b64 per neighbour; the neighbour offsets of a
+//    lane's cells are computed once per launch (no integer division in the loop).
+//  * exact mode: a near-tie cell is re-evaluated in float64 on the spot by its own lane behind a wave-uniform test
+//    (its 3x3 neighbourhood is in registers; 0.13 such cells per step of a 64-cell world).
+//  * reductions: the lifespan flag needs "some cover > threshold" - a compare and a lane mask, no reduction; sums and
+//    maximum are formed once, after the last step.
+// ---------------------------------------------------------------------------------------------
+constexpr int kEwSeg = 64;                                      // steps per LDS-resident constants segment
+constexpr int kEwMaxCells = 256;
+constexpr int kEwSlots = kEwMaxCells / 64;                      // cells per lane
+
+__host__ __device__ constexpr size_t episode_wave_shared_bytes() {      // P32 | Ls | use_table of one segment
+    return (size_t)kEwSeg * sizeof(PhysF32) + (size_t)kEwSeg * sizeof(double) + kEwSeg;
+}
+__host__ __device__ constexpr size_t episode_wave_world_bytes(int C, int N) {
+    // planes [2][C] (light, dark) float pairs | action-table slice of a segment | agents' ok masks
+    return (size_t)16 * C + ((size_t)kEwSeg * N + 15) / 16 * 16 + ((size_t)8 * N + 15) / 16 * 16;
+}
+
+template <bool EXACT>
+__global__ __launch_bounds__(256) void episode_wave(EpisodeIO io, int B, int N, int H, int W, int K, int policy_mode,
+                                                    int obs_mask, double agent_gamma, unsigned int thr, PhysF64 P64) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int C = H * W;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.x * 4 + wv;
+    const bool valid = b < B;                                   // (invalid waves still meet the segment barriers)
+    PhysF32* const sP32 = reinterpret_cast<PhysF32*>(smem);
+    double* const sLs = reinterpret_cast<double*>(smem + (size_t)kEwSeg * sizeof(PhysF32));
+    unsigned char* const sUT = smem + (size_t)kEwSeg * sizeof(PhysF32) + (size_t)kEwSeg * sizeof(double);
+    unsigned char* const wbase = smem + episode_wave_shared_bytes() + (size_t)wv * episode_wave_world_bytes(C, N);
+    float2* const planes = reinterpret_cast<float2*>(wbase);    // [2][C]
+    signed char* const sTab = reinterpret_cast<signed char*>(wbase + (size_t)16 * C);
+    unsigned long long* const sOk = reinterpret_cast<unsigned long long*>(wbase + (size_t)16 * C + ((size_t)kEwSeg * N + 15) / 16 * 16);
+    const bool with_agents = N > 0 && policy_mode != kPolicySkipAgents;
+    const bool any_table = policy_mode == kPolicyTable || (policy_mode != kPolicyZeros && io.use_table != nullptr);
+
+    // ---- this lane's cells and their neighbour offsets (float2 units inside a plane pair buffer) ----
+    int rowU[kEwSlots], rowM[kEwSlots], rowD[kEwSlots], colL[kEwSlots], colM[kEwSlots], colR[kEwSlots];
+    bool own[kEwSlots];
+#pragma unroll
+    for (int j = 0; j < kEwSlots; ++j) {
+        const int c = lane + 64 * j;
+        own[j] = valid && c < C;
+        const int cc0 = c < C ? c : 0;
+        const int r = cc0 / W, cc = cc0 - r * W;
+        rowU[j] = (r == 0 ? H - 1 : r - 1) * W; rowM[j] = r * W; rowD[j] = (r == H - 1 ? 0 : r + 1) * W;
+        colL[j] = cc == 0 ? W - 1 : cc - 1; colM[j] = cc; colR[j] = cc == W - 1 ? 0 : cc + 1;
+    }
+    int cur = 0;                                                // planes[cur*C ..]: the current state
+    if (valid) {
+#pragma unroll
+        for (int j = 0; j < kEwSlots; ++j)
+            if (own[j]) {
+                const int c = lane + 64 * j;
+                planes[c] = make_float2((float)io.L[(size_t)b * C + c], (float)io.D[(size_t)b * C + c]);
+            }
+    }
+    // agent n lives in lane n
+    const bool is_agent = valid && lane < N;
+    double ast = 0.0;
+    int ar = 0, ac = 0;
+    if (is_agent) {
+        ast = io.st[(size_t)b * N + lane];
+        ar = io.idx[((size_t)b * N + lane) * 2];
+        ac = io.idx[((size_t)b * N + lane) * 2 + 1];
+    }
+    const float thr_f = (float)thr;
+    unsigned int last_fix = 0;                                  // float64 re-evaluations of the last step (this lane)
+
+    for (int t0 = 0; t0 < K; t0 += kEwSeg) {
+        const int seg = min(kEwSeg, K - t0);
+        // ---- the segment's constants and this wave's slice of the action table into LDS ----
+        __syncthreads();                                        // (the previous segment's readers are done)
+        for (int i = tid; i < seg * (int)(sizeof(PhysF32) / 4); i += 256)
+            reinterpret_cast<unsigned int*>(sP32)[i] = reinterpret_cast<const unsigned int*>(io.P32 + t0)[i];
+        for (int i = tid; i < seg; i += 256) {
+            sLs[i] = io.Ls[t0 + i];
+            sUT[i] = (policy_mode != kPolicyZeros && io.use_table) ? io.use_table[t0 + i] : 0;
+        }
+        if (valid && with_agents && any_table && io.table)
+            for (int i = lane; i < seg * N; i += 64) {
+                const int tt = i / N, n = i - tt * N;
+                sTab[i] = io.table[((size_t)(t0 + tt) * B + b) * N + n];
+            }
+        __syncthreads();
+        unsigned long long alive_mask = 0ull, ok_mask = 0ull;   // bit i: step t0 + i (world: uniform; agent: this lane's)
+
+        for (int ts = 0; ts < seg; ++ts) {
+            float2* const pc = planes + cur * C;
+            float2* const pn = planes + (1 - cur) * C;
+            // ---- policy (ref agents/greedy.py:14-36 or the host-drawn table) + update_agents (ref :181-244) ----
+            if (with_agents) {
+                int a = 0;
+                bool graze = false;
+                int o = 0;
+                if (is_agent) {
+                    bool greedy = false, argmin = policy_mode == kPolicyArgmin;
+                    if (policy_mode == kPolicyTable || (policy_mode != kPolicyZeros && sUT[ts])) {
+                        a = sTab[ts * N + lane];                  // 0..8, or -1 / -2: (anti-)greedy choice
+                        greedy = a < 0;
+                        if (greedy) argmin = a == -2;
+                    } else if (policy_mode != kPolicyZeros) {
+                        greedy = true;
+                    }
+                    if (greedy) {
+                        // candidates in the reference's order: flat patch indices 3, 1, 7, 5 = (r,c-1) (r-1,c) (r+1,c) (r,c+1)
+                        const int rU = (ar == 0 ? H - 1 : ar - 1), rD = (ar == H - 1 ? 0 : ar + 1);
+                        const int cL = (ac == 0 ? W - 1 : ac - 1), cR = (ac == W - 1 ? 0 : ac + 1);
+                        const float2 c3 = pc[ar * W + cL], c1 = pc[rU * W + ac], c7 = pc[rD * W + ac], c5 = pc[ar * W + cR];
+                        const float2 cv[4] = {c3, c1, c7, c5};
+                        const int ck[4] = {3, 1, 7, 5};
+                        int best = 0;
+                        double bestv = 0.0;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            double v = 0.0;
+                            if ((obs_mask >> ck[i]) & 1)
+                                v = dw_permille_to_natural((double)cv[i].x) + dw_permille_to_natural((double)cv[i].y);
+                            if (i == 0 || (argmin ? v < bestv : v > bestv)) { best = i; bestv = v; }
+                        }
+                        a = 4 + best;
+                    }
+                    ast -= agent_gamma;
+                    if (ast > 0.0) {
+                        if (a != 8) {
+                            const int m = ((a % 4) + 4) % 4;
+                            if (m == 0) ac -= 1; else if (m == 1) ar -= 1; else if (m == 2) ar += 1; else ac += 1;
+                        }
+                        ar = ar < 0 ? ar + H : (ar >= H ? ar - H : ar);     // positions are in range (validated at upload): one wrap
+                        ac = ac < 0 ? ac + W : (ac >= W ? ac - W : ac);
+                        graze = a > 4;
+                    }
+                    o = ar * W + ac;
+                }
+                // the first agent (lowest index) to graze a cell eats it all: agents before me on my cell?
+                bool first = true;
+                for (int m = 0; m < N; ++m) {                    // wave-uniform
+                    const int om = __builtin_amdgcn_readlane(o, m);
+                    const int gm = __builtin_amdgcn_readlane((int)graze, m);
+                    if (gm && m < lane && om == o) first = false;
+                }
+                if (graze) {
+                    const float2 v = pc[o];
+                    if (first) ast += dw_permille_to_natural((double)v.x) + dw_permille_to_natural((double)v.y);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");    // every grazer has read its cell
+                __builtin_amdgcn_wave_barrier();
+                if (graze) pc[o] = make_float2(0.f, 0.f);
+                if (is_agent) ast = ast < 0.0 ? 0.0 : (ast > 1.0 ? 1.0 : ast);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+            // ---- forward (ref :434-461) ----
+            const PhysF32 P = sP32[ts];
+            const bool last = t0 + ts == K - 1;
+            bool alive_here = false;
+            unsigned int nfix = 0;
+#pragma unroll
+            for (int j = 0; j < kEwSlots; ++j) {
+                if (j * 64 >= C) break;                          // wave-uniform
+                float2 nb[9];
+                {
+                    const int rows[3] = {rowU[j], rowM[j], rowD[j]}, cols[3] = {colL[j], colM[j], colR[j]};
+#pragma unroll
+                    for (int a3 = 0; a3 < 3; ++a3)
+#pragma unroll
+                        for (int e3 = 0; e3 < 3; ++e3) nb[a3 * 3 + e3] = pc[rows[a3] + cols[e3]];
+                }
+                const float li = nb[4].x, di = nb[4].y;
+                const float El = (nb[1].x + nb[7].x) + (nb[3].x + nb[5].x);
+                const float Cl = (nb[0].x + nb[6].x) + (nb[2].x + nb[8].x);
+                const float Ed = (nb[1].y + nb[7].y) + (nb[3].y + nb[5].y);
+                const float Cd = (nb[0].y + nb[6].y) + (nb[2].y + nb[8].y);
+                const GrowthF32 g = growth_f32<EXACT || kFastSplit>(P, li, di, El, Cl, Ed, Cd);
+                float kl, kd;
+                if (EXACT) {
+                    bool tl, td;
+                    kl = finish_exact(P, li, g.gql, g.dKl, g.oml, tl);
+                    kd = finish_exact(P, di, g.gqd, g.dKd, g.omd, td);
+                    const bool tie = own[j] && (tl || td);
+                    if (__builtin_amdgcn_ballot_w64(tie) != 0ull) {           // wave-uniform: rare
+                        if (tie) {
+                            unsigned int wv9[9];
+#pragma unroll
+                            for (int i = 0; i < 9; ++i) wv9[i] = (unsigned)nb[i].x | ((unsigned)nb[i].y << 16);
+                            PhysF64 Q = P64;
+                            Q.L = sLs[ts];
+                            const NewCoverF64 o64 = cell_f64_lean(Q, wv9);
+                            kl = (float)dw_round3_k(o64.nl);
+                            kd = (float)dw_round3_k(o64.nd);
+                            ++nfix;
+                        }
+                    }
+                } else {
+                    kl = finish_fast(li, g.dKl, g.fl);
+                    kd = finish_fast(di, g.dKd, g.fd);
+                }
+                if (own[j]) {
+                    pn[lane + 64 * j] = make_float2(kl, kd);
+                    alive_here = alive_here || fmaxf(kl, kd) > thr_f;
+                }
+            }
+            if (last) last_fix = nfix;
+            // ---- per-step flags of the lifespan harness (nb greedy cell 2:46-52) ----
+            if (__builtin_amdgcn_ballot_w64(alive_here) != 0ull) alive_mask |= 1ull << ts;
+            if (is_agent) {
+                const double rw = ast * (ast > 0.0 ? 1.0 : 0.0);
+                if (!(rw < 0.1)) ok_mask |= 1ull << ts;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");        // the new plane is complete before anyone reads it
+            __builtin_amdgcn_wave_barrier();
+            cur = 1 - cur;
+        }
+        // ---- the segment's flags ----
+        if (valid) {
+            for (int i = lane; i < seg; i += 64) io.world_alive[(size_t)(t0 + i) * B + b] = (unsigned char)((alive_mask >> i) & 1ull);
+            if (N > 0) {
+                if (is_agent) sOk[lane] = ok_mask;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                for (int i = lane; i < seg * N; i += 64) {
+                    const int tt = i / N, n = i - tt * N;
+                    io.agent_ok[((size_t)(t0 + tt) * B + b) * N + n] = (unsigned char)((sOk[n] >> tt) & 1ull);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+
+    // ---- back to global memory: planes, the state before the last step (after its grazing), agents, reductions ----
+    if (valid) {
+        const float2* const pc = planes + cur * C;
+        const float2* const pp = planes + (1 - cur) * C;
+        float m = 0.f, sl = 0.f, sd = 0.f;
+#pragma unroll
+        for (int j = 0; j < kEwSlots; ++j)
+            if (own[j]) {
+                const int c = lane + 64 * j;
+                const float2 v = pc[c], w = pp[c];
+                io.L[(size_t)b * C + c] = (plane_t)v.x;
+                io.D[(size_t)b * C + c] = (plane_t)v.y;
+                io.prevL[(size_t)b * C + c] = (plane_t)w.x;
+                io.prevD[(size_t)b * C + c] = (plane_t)w.y;
+                m = fmaxf(m, fmaxf(v.x, v.y));
+                sl += v.x;
+                sd += v.y;
+            }
+        if (is_agent) {
+            io.st[(size_t)b * N + lane] = ast;
+            io.idx[((size_t)b * N + lane) * 2] = ar;
+            io.idx[((size_t)b * N + lane) * 2 + 1] = ac;
+        }
+        m = wave_max(m);
+        sl = wave_sum(sl);                                       // integers < 2^24: exact in any order
+        sd = wave_sum(sd);
+        const unsigned int nf = (unsigned int)wave_sum((float)last_fix);
+        if (lane == 0) {
+            io.stats[b].max_k = (unsigned int)m;
+            io.stats[b].sum_l = (unsigned long long)sl;
+            io.stats[b].sum_d = (unsigned long long)sd;
+            if (EXACT && nf) atomicAdd(io.fixups, (unsigned long long)nf);
+        }
+    }
+}
+
+}  // namespace dw

@@ -38,11 +38,6 @@ namespace dw {
 #ifndef DW_STREAM_WAVES_EXACT
 #define DW_STREAM_WAVES_EXACT 3
 #endif
-// (1: the exact kernel evaluates the cells of both rows of a block before reductions, stores and pushes - 3 % fewer
-// instructions, but measured 4.7 % SLOWER on C2 and 1 % faster on 64 x 4096^2: off)
-#ifndef DW_STREAM_EXACT_PAIRED
-#define DW_STREAM_EXACT_PAIRED 0
-#endif
 
 struct StripGeom {
     int B, H, W;
@@ -53,6 +48,7 @@ struct StripGeom {
     int chunk;                // ceil(nwg / 8): workgroups per XCD
     int qcap;                 // near-tie LDS queue capacity in use (<= kWaveQueueCap; tests shrink it)
     int lpw, wpr;             // packed mode (W < 256): lanes per world row (W/4), worlds per wave row (64 / lpw)
+    int force_rescan;         // tests: every exact strip takes the maximum's re-scan path (see `rescan_max` in stream_body)
 };
 
 struct Raw {                  // one row AS LOADED (binary16: 6 VGPRs; widened where it is consumed): own 4 columns
@@ -250,6 +246,17 @@ __device__ __forceinline__ void stream_body(const plane_t* __restrict__ inL, con
     const plane_t* pD = inD + woff;
     const int last_row = r0 + nr;                           // one past the strip: the bottom halo row
     float acc_max = 0.f, acc_l = 0.f, acc_d = 0.f;
+    // The strip's maximum.  The new values are non-negative float32 integers, so their BIT PATTERNS order like the values:
+    // the row loop keeps an integer maximum (one v_max3_i32 per cell; fmaxf is two more instructions per cell, it quiets a
+    // possible signalling NaN in each operand first).  Exact kernels: a near-tie cell's float32 value may be one quantum
+    // off, and round 3 kept it out of the maximum with a select per cell.  Now the row loop takes the maximum A over ALL
+    // float32 values and the sweeps, which see every near-tie cell's float32 value p and float64 value e, keep T = max p
+    // and E = max e: if A > T a cell whose float32 value is final attains A, and if E >= A a near-tie cell's float64
+    // value tops every float32 value - either way the strip's maximum is max(A, E).  Only when A == T and E < A (the
+    // cells that attain A are all near-tie cells and none keeps the value) the wave re-reads its finished, patched strip
+    // (`rescan_max`).  Packed exact strips (per-world maxima inside lane groups) keep the select.
+    constexpr bool IMAX = !(EXACT && HALO == 3);
+    int amax = 0;
     dw_f32x2 accp_l = dw_f32x2(0.f), accp_d = dw_f32x2(0.f);  // the row loop sums cell PAIRS (one packed add for two cells)
     unsigned int nq = 0;                                    // entries queued by this wave (uniform)
     // packed exact strips: what the queue sweeps change in the SUMS of the wave row's worlds (an entry's world is not
@@ -272,7 +279,8 @@ __device__ __forceinline__ void stream_body(const plane_t* __restrict__ inL, con
         Raw w;
         w.l = stream_load4_raw(rl + colq);
         w.d = stream_load4_raw(rd + colq);
-        if (HALO == 1 || HALO == 2) { w.hl = rl[hcol]; w.hd = rd[hcol]; } else { w.hl = (plane_t)0.f; w.hd = (plane_t)0.f; }
+        if (HALO == 1 || HALO == 2) { w.hl = rl[hcol]; w.hd = rd[hcol];
+        } else { w.hl = (plane_t)0.f; w.hd = (plane_t)0.f; }
         return w;
     };
     auto to_rows = [&](const Raw& w, Row4& L, Row4& D) {
@@ -299,12 +307,9 @@ __device__ __forceinline__ void stream_body(const plane_t* __restrict__ inL, con
         cells4<EXACT, SYM, unsigned long long>(P, upL, miL, dnL, upD, miD, dnD, ol, od, tie);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            if (EXACT) {
-                if (HALO >= 2) tie[i] &= active_mask;
-                acc_max = fmaxf(acc_max, in_mask(tie[i]) ? 0.f : fmaxf(ol[i], od[i]));
-            } else {
-                acc_max = fmaxf(acc_max, fmaxf(ol[i], od[i]));
-            }
+            if (EXACT && HALO >= 2) tie[i] &= active_mask;
+            if (IMAX) asm("v_max3_i32 %0, %0, %1, %2" : "+v"(amax) : "v"(ol[i]), "v"(od[i]));   // (the compiler builds a tree: 1.5 per cell)
+            else acc_max = fmaxf(acc_max, in_mask(tie[i]) ? 0.f : fmaxf(ol[i], od[i]));
         }
         accp_l += dw_f32x2{ol[0], ol[1]} + dw_f32x2{ol[2], ol[3]};      // integers < 2^24: exact in any order
         accp_d += dw_f32x2{od[0], od[1]} + dw_f32x2{od[2], od[3]};
@@ -347,44 +352,8 @@ __device__ __forceinline__ void stream_body(const plane_t* __restrict__ inL, con
             use[1] = load_raw(r0 + kk + 4);
         }
         __builtin_amdgcn_sched_barrier(0);                  // loads first, then the arithmetic
-        if constexpr (EXACT && DW_STREAM_EXACT_PAIRED != 0) {
-            // the cells of BOTH rows first - two independent row maps in one basic block, their transcendental chains
-            // overlap - then reductions, stores and, behind ONE wave-uniform test, the queue pushes of both rows
-            float olA[4], odA[4], olB[4], odB[4];
-            unsigned long long tieA[4], tieB[4];
-            cells4<EXACT, SYM, unsigned long long>(P, WL[s0], WL[s1], WL[s2], WD[s0], WD[s1], WD[s2], olA, odA, tieA);
-            cells4<EXACT, SYM, unsigned long long>(P, WL[s1], WL[s2], WL[s3], WD[s1], WD[s2], WD[s3], olB, odB, tieB);
-            unsigned long long any = 0ull;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (HALO >= 2) { tieA[i] &= active_mask; tieB[i] &= active_mask; }
-                acc_max = fmaxf(acc_max, in_mask(tieA[i]) ? 0.f : fmaxf(olA[i], odA[i]));
-                acc_max = fmaxf(acc_max, in_mask(tieB[i]) ? 0.f : fmaxf(olB[i], odB[i]));
-                any |= tieA[i] | tieB[i];
-            }
-            accp_l += (dw_f32x2{olA[0], olA[1]} + dw_f32x2{olA[2], olA[3]}) + (dw_f32x2{olB[0], olB[1]} + dw_f32x2{olB[2], olB[3]});
-            accp_d += (dw_f32x2{odA[0], odA[1]} + dw_f32x2{odA[2], odA[3]}) + (dw_f32x2{odB[0], odB[1]} + dw_f32x2{odB[2], odB[3]});
-            if (HALO < 2 || active) {
-                const size_t off = woff + (size_t)(r0 + kk) * G.W + colq;
-                stream_store4(outL + off, make_float4(olA[0], olA[1], olA[2], olA[3]));
-                stream_store4(outD + off, make_float4(odA[0], odA[1], odA[2], odA[3]));
-                stream_store4(outL + off + G.W, make_float4(olB[0], olB[1], olB[2], olB[3]));
-                stream_store4(outD + off + G.W, make_float4(odB[0], odB[1], odB[2], odB[3]));
-            }
-            if (any != 0ull) {
-                queue_tie<0>(tieA[0], nq, q, (unsigned)G.qcap, world, r0 + kk, colq, WL[s0], WL[s1], WL[s2], WD[s0], WD[s1], WD[s2], olA, odA);
-                queue_tie<1>(tieA[1], nq, q, (unsigned)G.qcap, world, r0 + kk, colq, WL[s0], WL[s1], WL[s2], WD[s0], WD[s1], WD[s2], olA, odA);
-                queue_tie<2>(tieA[2], nq, q, (unsigned)G.qcap, world, r0 + kk, colq, WL[s0], WL[s1], WL[s2], WD[s0], WD[s1], WD[s2], olA, odA);
-                queue_tie<3>(tieA[3], nq, q, (unsigned)G.qcap, world, r0 + kk, colq, WL[s0], WL[s1], WL[s2], WD[s0], WD[s1], WD[s2], olA, odA);
-                queue_tie<0>(tieB[0], nq, q, (unsigned)G.qcap, world, r0 + kk + 1, colq, WL[s1], WL[s2], WL[s3], WD[s1], WD[s2], WD[s3], olB, odB);
-                queue_tie<1>(tieB[1], nq, q, (unsigned)G.qcap, world, r0 + kk + 1, colq, WL[s1], WL[s2], WL[s3], WD[s1], WD[s2], WD[s3], olB, odB);
-                queue_tie<2>(tieB[2], nq, q, (unsigned)G.qcap, world, r0 + kk + 1, colq, WL[s1], WL[s2], WL[s3], WD[s1], WD[s2], WD[s3], olB, odB);
-                queue_tie<3>(tieB[3], nq, q, (unsigned)G.qcap, world, r0 + kk + 1, colq, WL[s1], WL[s2], WL[s3], WD[s1], WD[s2], WD[s3], olB, odB);
-            }
-        } else {
-            row_math(WL[s0], WL[s1], WL[s2], WD[s0], WD[s1], WD[s2], kk);
-            row_math(WL[s1], WL[s2], WL[s3], WD[s1], WD[s2], WD[s3], kk + 1);
-        }
+        row_math(WL[s0], WL[s1], WL[s2], WD[s0], WD[s1], WD[s2], kk);
+        row_math(WL[s1], WL[s2], WL[s3], WD[s1], WD[s2], WD[s3], kk + 1);
         __builtin_amdgcn_sched_barrier(0);
         to_rows(use[0], WL[s0], WD[s0]);                    // rows kk+3, kk+4: window rows 2, 3 of the next block
         to_rows(use[1], WL[s1], WD[s1]);
@@ -396,6 +365,8 @@ __device__ __forceinline__ void stream_body(const plane_t* __restrict__ inL, con
     const int flush_at = G.qcap >> 1;
     float fix_max = 0.f, fix_l = 0.f, fix_d = 0.f;          // what the sweeps change in this lane's reductions (their
                                                             // entries are not the lane's own cells: kept apart from acc_*)
+    float fix_tmax = 0.f;                                   // T: the largest float32 value of a swept entry
+    unsigned int swept = 0;                                 // entries swept so far (uniform)
     auto sweep_queue = [&]() {
         if (nq > (unsigned)G.qcap) redo = true;
         if (!redo && nq) {
@@ -421,14 +392,17 @@ __device__ __forceinline__ void stream_body(const plane_t* __restrict__ inL, con
                     if (dl) atomicAdd(&pfix[2 * pwe], dl);
                     if (dd) atomicAdd(&pfix[2 * pwe + 1], dd);
                 } else {
-                    fix_l += kl - (float)(f32v & 0xffffu);
-                    fix_d += kd - (float)(f32v >> 16);
+                    const float pl = (float)(f32v & 0xffffu), pd = (float)(f32v >> 16);
+                    fix_l += kl - pl;
+                    fix_d += kd - pd;
                     fix_max = fmaxf(fix_max, fmaxf(kl, kd));
+                    fix_tmax = fmaxf(fix_tmax, fmaxf(pl, pd));
                 }
             }
             if (lane == 0) atomicAdd(fixups, (unsigned long long)nq);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the queue is reused: reads above before later pushes
             __builtin_amdgcn_wave_barrier();
+            swept += nq;
         }
         nq = 0;
     };
@@ -448,6 +422,7 @@ __device__ __forceinline__ void stream_body(const plane_t* __restrict__ inL, con
     }
     acc_l = accp_l.x + accp_l.y;
     acc_d = accp_d.x + accp_d.y;
+    if (IMAX) acc_max = __int_as_float(amax);
     if (HALO >= 2 && !active) { acc_max = 0.f; acc_l = 0.f; acc_d = 0.f; }
 
     // ---- exact mode: the entries of the strip's last rows; a strip that lost entries: whole in float64 ----
@@ -456,7 +431,42 @@ __device__ __forceinline__ void stream_body(const plane_t* __restrict__ inL, con
         if (!redo) {
             acc_l += fix_l;
             acc_d += fix_d;
-            acc_max = fmaxf(acc_max, fix_max);
+            if (IMAX) {
+                // A / T / E of the comment at `amax`; all three wave-uniform after the shuffles
+                const float aw = wave_max(acc_max), tw = wave_max(fix_tmax), ew = wave_max(fix_max);
+                // aw > tw: a cell whose float32 value is final attains A; ew >= aw: some near-tie cell's float64 value
+                // is at least A, hence at least every final float32 value.  Either way the maximum is max(A, E).
+                if (__builtin_expect((swept != 0 && aw == tw && ew < aw) || G.force_rescan, 0)) {
+                    // rescan_max: the only cells that attain A are near-tie cells, and none of them keeps the value
+                    // (on developed states: well under 1 % of the strips).  Every row store and every patch of this
+                    // wave has reached L2 (vmcnt(0)); agent-scope loads read them back past the vector cache, eight
+                    // rows in flight at a time.
+                    wait_row_stores_before_patching();
+                    float m = 0.f;
+                    for (int k0 = 0; k0 < nr; k0 += 8) {
+                        unsigned long long wl[8], wd[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const int kk = min(k0 + j, nr - 1);
+                            const size_t off = woff + (size_t)(r0 + kk) * G.W + colq;
+                            wl[j] = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(outL + off), __ATOMIC_RELAXED,
+                                                      __HIP_MEMORY_SCOPE_AGENT);
+                            wd[j] = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(outD + off), __ATOMIC_RELAXED,
+                                                      __HIP_MEMORY_SCOPE_AGENT);
+                        }
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const float4 fl = widen4(__builtin_bit_cast(dw_f16x4, wl[j])), fd = widen4(__builtin_bit_cast(dw_f16x4, wd[j]));
+                            m = fmaxf(m, fmaxf(fmaxf(fmaxf(fl.x, fl.y), fmaxf(fl.z, fl.w)), fmaxf(fmaxf(fd.x, fd.y), fmaxf(fd.z, fd.w))));
+                        }
+                    }
+                    acc_max = (HALO < 2 || active) ? m : 0.f;
+                } else {
+                    acc_max = fmaxf(aw, ew);
+                }
+            } else {
+                acc_max = fmaxf(acc_max, fix_max);
+            }
             if (PACK) {                                     // the sweeps' corrections of the wave row's worlds
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
