@@ -106,6 +106,8 @@ struct dw_handle {
     size_t scratch_bytes = 0;
     unsigned char* ep_buf = nullptr;  // device staging of dw_run_episode (schedules, tables, flags)
     size_t ep_bytes = 0;
+    unsigned char* ep_pinned = nullptr;   // page-locked host image of ep_buf (LDS-resident episode kernels: ONE upload
+    size_t ep_pinned_bytes = 0;           // and ONE download per chunk instead of six pageable copies)
     double* reward_d = nullptr;       // [B][N]
     unsigned char* done_d = nullptr;  // [B][N]
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -953,6 +955,7 @@ int dw_destroy(dw_handle* h) {
     (void)hipFree(h->idx); (void)hipFree(h->st); (void)hipFree(h->action); (void)hipFree(h->action_tmp);
     (void)hipFree(h->reward_d); (void)hipFree(h->done_d);
     if (h->pinned) (void)hipHostFree(h->pinned);
+    if (h->ep_pinned) (void)hipHostFree(h->ep_pinned);
     (void)hipFree(h->snapL); (void)hipFree(h->snapD); (void)hipFree(h->snap_idx); (void)hipFree(h->snap_st);
     (void)hipFree(h->snapPL); (void)hipFree(h->snapPD);
     (void)hipFree(h->snap_stats);
@@ -2007,23 +2010,51 @@ static int run_episode_impl(dw_handle* h, int32_t nsteps, const double* L_schedu
     const size_t world_bytes = wave_kernel ? episode_wave_world_bytes(C, N) : episode_world_bytes(C, N);
     const size_t lds = world_bytes * wpb + (wave_kernel ? episode_wave_shared_bytes() : 0);
     NEED(lds <= 160 * 1024, DW_EINVAL, "too many agents for the LDS-resident episode kernel");
-    // device staging: [P32 K][Ls K][use_table K][table K*B*N][world_alive K*B][agent_ok K*B*N]
+    // device staging: [P32 K][Ls K][use_table K][table K*B*N] | [world_alive K*B][agent_ok K*B*N]
     const size_t K = (size_t)nsteps, bn = (size_t)B * N;
     auto up = [](size_t v) { return (v + 255) / 256 * 256; };
     const size_t o_p32 = 0, o_ls = up(o_p32 + sizeof(PhysF32) * K), o_ut = up(o_ls + sizeof(double) * K);
     const size_t o_tab = up(o_ut + K), o_wa = up(o_tab + K * bn), o_ok = up(o_wa + K * B), total = up(o_ok + K * bn);
     if (int erc = ensure_ep_buf(h, total)) return erc;
-    std::vector<PhysF32> p32(K);
+    // The inputs are assembled in a page-locked image of the staging buffer and go up in ONE copy; the flags come back
+    // in ONE copy (round 3: four pageable uploads, a memset and two pageable downloads per chunk - 88 us of host time
+    // per 64-step chunk of 1000 8x8 worlds against 116 us of kernel).  Beyond 64 MiB: straight from / to the caller's arrays.
+    const bool staged = total <= ((size_t)64 << 20);
+    if (staged && h->ep_pinned_bytes < total) {
+        if (h->ep_pinned) HIPCHK(hipHostFree(h->ep_pinned));
+        h->ep_pinned = nullptr; h->ep_pinned_bytes = 0;
+        size_t want = h->ep_pinned_bytes ? h->ep_pinned_bytes * 2 : ((size_t)1 << 20);
+        if (want < total) want = total;
+        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h->ep_pinned), want, hipHostMallocDefault));
+        h->ep_pinned_bytes = want;
+    }
+    std::vector<PhysF32> p32_own;
+    std::vector<unsigned char> ut_own;
+    PhysF32* p32 = nullptr;
+    unsigned char* ut = nullptr;
+    if (staged) {
+        p32 = reinterpret_cast<PhysF32*>(h->ep_pinned + o_p32);
+        ut = h->ep_pinned + o_ut;
+    } else {
+        p32_own.resize(K); ut_own.resize(K);
+        p32 = p32_own.data(); ut = ut_own.data();
+    }
     for (size_t t = 0; t < K; ++t) p32[t] = derive_f32(p, L_schedule[t]);
-    std::vector<unsigned char> ut(K, 0);
-    if (use_table) std::memcpy(ut.data(), use_table, K);
-    SyncOnExit guard(h->stream);                              // p32 / ut above and the caller's arrays
-    HIPCHK(hipMemcpyAsync(h->ep_buf + o_p32, p32.data(), sizeof(PhysF32) * K, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->ep_buf + o_ls, L_schedule, sizeof(double) * K, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->ep_buf + o_ut, ut.data(), K, hipMemcpyHostToDevice, h->stream));
-    if (table && bn) HIPCHK(hipMemcpyAsync(h->ep_buf + o_tab, table, K * bn, hipMemcpyHostToDevice, h->stream));
+    if (use_table) std::memcpy(ut, use_table, K); else std::memset(ut, 0, K);
+    SyncOnExit guard(h->stream);                              // the images above and the caller's arrays
+    if (staged) {
+        std::memcpy(h->ep_pinned + o_ls, L_schedule, sizeof(double) * K);
+        if (table && bn) std::memcpy(h->ep_pinned + o_tab, table, K * bn);
+        HIPCHK(hipMemcpyAsync(h->ep_buf, h->ep_pinned, (table && bn) ? o_tab + K * bn : o_ut + K, hipMemcpyHostToDevice, h->stream));
+    } else {
+        HIPCHK(hipMemcpyAsync(h->ep_buf + o_p32, p32, sizeof(PhysF32) * K, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->ep_buf + o_ls, L_schedule, sizeof(double) * K, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->ep_buf + o_ut, ut, K, hipMemcpyHostToDevice, h->stream));
+        if (table && bn) HIPCHK(hipMemcpyAsync(h->ep_buf + o_tab, table, K * bn, hipMemcpyHostToDevice, h->stream));
+    }
     StatsDev* stats = h->stats2[h->sp];
-    HIPCHK(hipMemsetAsync(stats, 0, sizeof(StatsDev) * (B + 1), h->stream));
+    // (every world's record is assigned by its kernel; only the float64 counter behind them is accumulated)
+    HIPCHK(hipMemsetAsync(&stats[B], 0, sizeof(StatsDev), h->stream));
     EpisodeIO io;
     const int cur = h->cur, prev = 1 - h->cur;
     io.L = h->L16[cur]; io.D = h->D16[cur]; io.prevL = h->L16[prev]; io.prevD = h->D16[prev];
@@ -2043,9 +2074,13 @@ static int run_episode_impl(dw_handle* h, int32_t nsteps, const double* L_schedu
         io.use_table = use_table ? h->ep_buf + o_ut : nullptr;
         io.table = (table && bn) ? io.table : nullptr;
         auto kern = ex ? episode_wave<true> : episode_wave<false>;
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, h->stream, io, B, N, p.height, p.width, nsteps, policy_mode,
-                           p.obs_mask, p.agent_gamma, threshold_k, P64);
+        static size_t lds_set[2] = {0, 0};                      // the attribute only ever has to grow
+        if (lds_set[ex] < lds) {
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            lds_set[ex] = lds;
+        }
+        const EpisodeWaveArgs A{io, B, N, p.height, p.width, nsteps, policy_mode, p.obs_mask, threshold_k, p.agent_gamma, P64};
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, h->stream, A);
     } else {
         auto kern = ex ? episode_small<true> : episode_small<false>;
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -2053,14 +2088,26 @@ static int run_episode_impl(dw_handle* h, int32_t nsteps, const double* L_schedu
                            p.obs_mask, p.agent_gamma, threshold_k, P64);
     }
     HIPCHK(hipGetLastError());
-    if (world_alive) HIPCHK(hipMemcpyAsync(world_alive, h->ep_buf + o_wa, K * B, hipMemcpyDeviceToHost, h->stream));
-    if (agent_ok && bn) HIPCHK(hipMemcpyAsync(agent_ok, h->ep_buf + o_ok, K * bn, hipMemcpyDeviceToHost, h->stream));
+    const bool want_ok = agent_ok && bn;
+    if (staged) {
+        if (world_alive || want_ok) {
+            const size_t lo = world_alive ? o_wa : o_ok, hi = want_ok ? o_ok + K * bn : o_wa + K * B;
+            HIPCHK(hipMemcpyAsync(h->ep_pinned + lo, h->ep_buf + lo, hi - lo, hipMemcpyDeviceToHost, h->stream));
+        }
+    } else {
+        if (world_alive) HIPCHK(hipMemcpyAsync(world_alive, h->ep_buf + o_wa, K * B, hipMemcpyDeviceToHost, h->stream));
+        if (want_ok) HIPCHK(hipMemcpyAsync(agent_ok, h->ep_buf + o_ok, K * bn, hipMemcpyDeviceToHost, h->stream));
+    }
     h->unq = OWN_NONE;
     h->stepped = true;
     h->L_last = L_schedule[K - 1];
     release_unquantised(h);
     HIPCHK(hipStreamSynchronize(h->stream));      // flags are returned
     guard.disarm();
+    if (staged) {
+        if (world_alive) std::memcpy(world_alive, h->ep_pinned + o_wa, K * B);
+        if (want_ok) std::memcpy(agent_ok, h->ep_pinned + o_ok, K * bn);
+    }
     return DW_OK;
 }
 

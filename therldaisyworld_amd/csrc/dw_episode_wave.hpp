@@ -2,6 +2,7 @@
 // sweep's 8x8 grids, the ES trainers' 16x16), one WAVE per world.
 #pragma once
 #include "dw_episode.hpp"
+#include "dw_step_stream.hpp"
 
 namespace dw {
 
@@ -41,9 +42,22 @@ __host__ __device__ constexpr size_t episode_wave_world_bytes(int C, int N) {
     return (size_t)16 * C + ((size_t)kEwSeg * N + 15) / 16 * 16 + ((size_t)8 * N + 15) / 16 * 16;
 }
 
+// ONE argument struct: the float64 constants are needed only by the rare near-tie path and are read from the kernarg
+// segment there (as by-value arguments they would sit in 34 SGPRs for the whole launch; `kernarg_struct`, dw_step_stream.hpp)
+struct EpisodeWaveArgs {
+    EpisodeIO io;
+    int B, N, H, W, K, policy_mode, obs_mask;
+    unsigned int thr;
+    double agent_gamma;
+    PhysF64 P64;                                                // cold
+};
+
 template <bool EXACT>
-__global__ __launch_bounds__(256) void episode_wave(EpisodeIO io, int B, int N, int H, int W, int K, int policy_mode,
-                                                    int obs_mask, double agent_gamma, unsigned int thr, PhysF64 P64) {
+__global__ __launch_bounds__(256) void episode_wave(EpisodeWaveArgs A) {
+    const EpisodeIO& io = A.io;
+    const int B = A.B, N = A.N, H = A.H, W = A.W, K = A.K, policy_mode = A.policy_mode, obs_mask = A.obs_mask;
+    const unsigned int thr = A.thr;
+    const double agent_gamma = A.agent_gamma;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int C = H * W;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -83,6 +97,7 @@ __global__ __launch_bounds__(256) void episode_wave(EpisodeIO io, int B, int N, 
     }
     // agent n lives in lane n
     const bool is_agent = valid && lane < N;
+    const int alane = N > 0 ? min(lane, N - 1) : 0;             // (lanes without an agent shadow the last one's table entry)
     double ast = 0.0;
     int ar = 0, ac = 0;
     if (is_agent) {
@@ -110,74 +125,70 @@ __global__ __launch_bounds__(256) void episode_wave(EpisodeIO io, int B, int N, 
             }
         __syncthreads();
         unsigned long long alive_mask = 0ull, ok_mask = 0ull;   // bit i: step t0 + i (world: uniform; agent: this lane's)
+        const unsigned long long ut_mask = __builtin_amdgcn_ballot_w64(lane < seg && sUT[lane] != 0);   // steps that take the table
 
         for (int ts = 0; ts < seg; ++ts) {
             float2* const pc = planes + cur * C;
             float2* const pn = planes + (1 - cur) * C;
+            // Everything this step reads from LDS before the physics is issued HERE, in one round trip: the step's
+            // constants, the agent's action byte and the five cells an agent can see or reach.
+            const PhysF32 P = sP32[ts];
             // ---- policy (ref agents/greedy.py:14-36 or the host-drawn table) + update_agents (ref :181-244) ----
             if (with_agents) {
-                int a = 0;
-                bool graze = false;
-                int o = 0;
-                if (is_agent) {
-                    bool greedy = false, argmin = policy_mode == kPolicyArgmin;
-                    if (policy_mode == kPolicyTable || (policy_mode != kPolicyZeros && sUT[ts])) {
-                        a = sTab[ts * N + lane];                  // 0..8, or -1 / -2: (anti-)greedy choice
-                        greedy = a < 0;
-                        if (greedy) argmin = a == -2;
-                    } else if (policy_mode != kPolicyZeros) {
-                        greedy = true;
-                    }
-                    if (greedy) {
-                        // candidates in the reference's order: flat patch indices 3, 1, 7, 5 = (r,c-1) (r-1,c) (r+1,c) (r,c+1)
-                        const int rU = (ar == 0 ? H - 1 : ar - 1), rD = (ar == H - 1 ? 0 : ar + 1);
-                        const int cL = (ac == 0 ? W - 1 : ac - 1), cR = (ac == W - 1 ? 0 : ac + 1);
-                        const float2 c3 = pc[ar * W + cL], c1 = pc[rU * W + ac], c7 = pc[rD * W + ac], c5 = pc[ar * W + cR];
-                        const float2 cv[4] = {c3, c1, c7, c5};
-                        const int ck[4] = {3, 1, 7, 5};
-                        int best = 0;
-                        double bestv = 0.0;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            double v = 0.0;
-                            if ((obs_mask >> ck[i]) & 1)
-                                v = dw_permille_to_natural((double)cv[i].x) + dw_permille_to_natural((double)cv[i].y);
-                            if (i == 0 || (argmin ? v < bestv : v > bestv)) { best = i; bestv = v; }
-                        }
-                        a = 4 + best;
-                    }
-                    ast -= agent_gamma;
-                    if (ast > 0.0) {
-                        if (a != 8) {
-                            const int m = ((a % 4) + 4) % 4;
-                            if (m == 0) ac -= 1; else if (m == 1) ar -= 1; else if (m == 2) ar += 1; else ac += 1;
-                        }
-                        ar = ar < 0 ? ar + H : (ar >= H ? ar - H : ar);     // positions are in range (validated at upload): one wrap
-                        ac = ac < 0 ? ac + W : (ac >= W ? ac - W : ac);
-                        graze = a > 4;
-                    }
-                    o = ar * W + ac;
-                }
+                // Straight-line, select-based code for every lane (lanes that hold no agent work on agent 0's position and
+                // are masked at the end): a lone wave per SIMD pays ~20 cycles for every taken branch, and the branchy
+                // form of this block was half of the step's instructions.
+                const bool from_table = policy_mode == kPolicyTable || ((ut_mask >> ts) & 1ull);           // wave-uniform
+                const int tab = (int)sTab[ts * N + alane];       // 0..8, or -1 / -2: (anti-)greedy choice (unused unless from_table)
+                // the reference's candidate order: flat patch indices 3, 1, 7, 5 = (r,c-1) (r-1,c) (r+1,c) (r,c+1) - which is also
+                // the order of the move codes a % 4 = 0, 1, 2, 3: the cell an agent lands on is always one of these four or
+                // its own, so its cover is already in registers when the agent grazes
+                const int rU = (ar == 0 ? H - 1 : ar - 1), rD = (ar == H - 1 ? 0 : ar + 1);
+                const int cL = (ac == 0 ? W - 1 : ac - 1), cR = (ac == W - 1 ? 0 : ac + 1);
+                const int rowo = ar * W;
+                const float2 cv0 = pc[rowo + cL], cv1 = pc[rU * W + ac], cv2 = pc[rD * W + ac], cv3 = pc[rowo + cR];
+                const float2 own_cell = pc[rowo + ac];
+                const double nat0 = dw_permille_to_natural((double)cv0.x) + dw_permille_to_natural((double)cv0.y);
+                const double nat1 = dw_permille_to_natural((double)cv1.x) + dw_permille_to_natural((double)cv1.y);
+                const double nat2 = dw_permille_to_natural((double)cv2.x) + dw_permille_to_natural((double)cv2.y);
+                const double nat3 = dw_permille_to_natural((double)cv3.x) + dw_permille_to_natural((double)cv3.y);
+                const double nat_own = dw_permille_to_natural((double)own_cell.x) + dw_permille_to_natural((double)own_cell.y);
+                const bool greedy = from_table ? tab < 0 : policy_mode != kPolicyZeros;
+                const bool argmin = (from_table && tab < 0) ? tab == -2 : policy_mode == kPolicyArgmin;
+                // first maximum / minimum over the (masked) candidates, as np.argmax / np.argmin
+                const double v0 = ((obs_mask >> 3) & 1) ? nat0 : 0.0, v1 = ((obs_mask >> 1) & 1) ? nat1 : 0.0;
+                const double v2 = ((obs_mask >> 7) & 1) ? nat2 : 0.0, v3 = ((obs_mask >> 5) & 1) ? nat3 : 0.0;
+                int best = 0;
+                double bestv = v0;
+                { const bool bt = argmin ? v1 < bestv : v1 > bestv; best = bt ? 1 : best; bestv = bt ? v1 : bestv; }
+                { const bool bt = argmin ? v2 < bestv : v2 > bestv; best = bt ? 2 : best; bestv = bt ? v2 : bestv; }
+                { const bool bt = argmin ? v3 < bestv : v3 > bestv; best = bt ? 3 : best; }
+                const int a = greedy ? 4 + best : (from_table ? tab : 0);
+                const double s0 = ast - agent_gamma;
+                const bool alive = is_agent && s0 > 0.0;
+                const int m = a & 3;                             // a in 0..8
+                const bool stay = a == 8;
+                const double gain = stay ? nat_own : (m == 0 ? nat0 : (m == 1 ? nat1 : (m == 2 ? nat2 : nat3)));
+                const int nr = stay ? ar : (m == 1 ? rU : (m == 2 ? rD : ar));
+                const int nc = stay ? ac : (m == 0 ? cL : (m == 3 ? cR : ac));
+                ar = alive ? nr : ar;
+                ac = alive ? nc : ac;
+                const bool graze = alive && a > 4;
+                const int o = ar * W + ac;
                 // the first agent (lowest index) to graze a cell eats it all: agents before me on my cell?
                 bool first = true;
-                for (int m = 0; m < N; ++m) {                    // wave-uniform
-                    const int om = __builtin_amdgcn_readlane(o, m);
-                    const int gm = __builtin_amdgcn_readlane((int)graze, m);
-                    if (gm && m < lane && om == o) first = false;
+                for (int mm = 0; mm < N; ++mm) {                 // wave-uniform
+                    const int om = __builtin_amdgcn_readlane(o, mm);
+                    const int gm = __builtin_amdgcn_readlane((int)graze, mm);
+                    first = first && !(gm && mm < lane && om == o);
                 }
-                if (graze) {
-                    const float2 v = pc[o];
-                    if (first) ast += dw_permille_to_natural((double)v.x) + dw_permille_to_natural((double)v.y);
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");    // every grazer has read its cell
-                __builtin_amdgcn_wave_barrier();
-                if (graze) pc[o] = make_float2(0.f, 0.f);
-                if (is_agent) ast = ast < 0.0 ? 0.0 : (ast > 1.0 ? 1.0 : ast);
+                const double s1 = (graze && first) ? s0 + gain : s0;
+                if (is_agent) ast = s1 < 0.0 ? 0.0 : (s1 > 1.0 ? 1.0 : s1);
+                if (graze) pc[o] = make_float2(0.f, 0.f);       // (every read above precedes it in this wave's program order)
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
             }
             // ---- forward (ref :434-461) ----
-            const PhysF32 P = sP32[ts];
             const bool last = t0 + ts == K - 1;
             bool alive_here = false;
             unsigned int nfix = 0;
@@ -209,7 +220,9 @@ __global__ __launch_bounds__(256) void episode_wave(EpisodeIO io, int B, int N, 
                             unsigned int wv9[9];
 #pragma unroll
                             for (int i = 0; i < 9; ++i) wv9[i] = (unsigned)nb[i].x | ((unsigned)nb[i].y << 16);
-                            PhysF64 Q = P64;
+                            const EpisodeWaveArgs* cold = &kernarg_struct<EpisodeWaveArgs>();
+                            asm volatile("" : "+s"(cold));           // (keeps the 17 scalar loads inside this block)
+                            PhysF64 Q = cold->P64;
                             Q.L = sLs[ts];
                             const NewCoverF64 o64 = cell_f64_lean(Q, wv9);
                             kl = (float)dw_round3_k(o64.nl);

@@ -299,13 +299,14 @@ class Engine:
             raise ValueError("use_table must have shape (K,)")
         if tb is not None and tb.shape != (K, self.B, self.N):
             raise ValueError(f"table must have shape {(K, self.B, self.N)}")
-        alive = np.zeros((K, self.B), dtype=np.uint8) if world_flags else None
-        ok = np.zeros((K, self.B, self.N), dtype=np.uint8)
+        # (the library writes every flag as 0 / 1: the uint8 arrays are returned as bool VIEWS, no second pass)
+        alive = np.empty((K, self.B), dtype=np.uint8) if world_flags else None
+        ok = np.empty((K, self.B, self.N), dtype=np.uint8)
         self._check(self._lib.dw_run_episode(
             self._h, K, _ffi.ptr_d(Ls), int(policy_mode), _ffi.ptr_u8(ut),
             None if tb is None else tb.ctypes.data_as(C.POINTER(C.c_int8)), int(threshold_k), _ffi.ptr_u8(alive),
             _ffi.ptr_u8(ok) if self.N else None))
-        return (None if alive is None else alive.astype(bool)), ok.astype(bool)
+        return (None if alive is None else alive.view(np.bool_)), ok.view(np.bool_)
 
     def run_episode_mlp(self, L_schedule, params, member_a=None, member_b=None, split=None, L_init=0.75):
         """K device-resident steps with MLP policies: agents [0, split) of world b use parameter set
