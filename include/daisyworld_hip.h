@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define DW_ABI_VERSION 3
+#define DW_ABI_VERSION 4
 
 /* ---- error codes ---------------------------------------------------------------------------- */
 enum {
@@ -144,6 +144,12 @@ int dw_get_params(const dw_handle* h, dw_params* out);
 
 const char* dw_last_error(void);
 int dw_abi_version(void);
+
+/* Page-locked host memory (hipHostMalloc) for buffers the library fills or reads: a download into it runs at the full
+ * host-link rate, without the driver's staging copies (a pageable 4 MB reward block of dw_run_episode_mlp: 0.2 ms
+ * instead of 0.5-2 ms, box dependent).  No reference counterpart; needs a gfx950 device (DW_ENODEVICE otherwise). */
+int dw_pinned_alloc(size_t bytes, void** out);
+int dw_pinned_free(void* p);
 /* Hash of the sources + compiler flags this library was built from (16 hex digits; "unknown" for a build
  * that did not go through therldaisyworld_amd/build.py).  build.py rebuilds when it differs from the
  * sources in the tree, so a stale binary cannot run under newer host code. */
@@ -320,7 +326,10 @@ int dw_policy_mlp_population(dw_handle* h, const double* params, int32_t n_membe
  * observations' temperature channels if no step has been taken yet.  Worlds of H*W <= 4096 cells run the chunk as
  * ONE launch with the worlds resident in LDS (csrc/dw_episode.hpp: episode_mlp) once the state and the retained
  * previous state are quantised - i.e. from the third step of an episode on; larger worlds and the first two
- * steps take one launch sequence per step.  Same results either way. */
+ * steps take one launch sequence per step.  Same results either way.
+ * ABI 4: `params` may be NULL - the parameter sets of the last call on this handle that passed them stay on the device
+ * and are used again (n_members must be the same): a fitness harness uploads a population once per generation, not
+ * once per chunk.  `reward` / `done` in page-locked memory (dw_pinned_alloc) are filled without a staging copy. */
 int dw_run_episode_mlp(dw_handle* h, int32_t nsteps, const double* L_schedule, const double* params /* [n_members][1808] */,
                        int32_t n_members, const int32_t* member_a /* [B] */, const int32_t* member_b /* [B] */,
                        int32_t split, double L_init, double* reward /* [K][B][N] */, uint8_t* done /* [K][B][N] */);

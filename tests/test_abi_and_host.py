@@ -351,3 +351,21 @@ int main() {
                            "-o", str(exe)])
     out = subprocess.run([str(exe)], capture_output=True, text=True)
     assert out.returncode == 0 and out.stdout.strip() == "ok", (out.returncode, out.stdout)
+
+
+def test_division_free_permille_quotient_is_exact_below_2_pow_22(tmp_path):
+    """dw_div1000 / dw_permille_to_natural (csrc/dw_physics.hpp): k * 0.001 with one Newton correction is the correctly
+    rounded k / 1000.0 for every integer |k| < 2^22 - per-mille covers (<= 1000) and rounded temperatures in
+    milli-kelvin (<= 4194 K).  Checked exhaustively by the same two fma operations compiled for the host."""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("gcc not available")
+    src = tmp_path / "chk.c"
+    src.write_text(
+        "#include <stdio.h>\n#include <math.h>\n"
+        "int main(void){ long bad = 0; for (long k = -(1L<<22) + 1; k < (1L<<22); ++k) { double kk = (double)k, r = 0.001,"
+        " q = kk * r, v = fma(fma(-q, 1000.0, kk), r, q); if (v != kk / 1000.0) ++bad; } printf(\"%ld\\n\", bad); return 0; }\n")
+    exe = tmp_path / "chk"
+    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-o", str(exe), str(src), "-lm"])
+    assert subprocess.check_output([str(exe)]).strip() == b"0"

@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DW_LIB", os.path.join(_HERE, "libdaisyworld_hip.so"))   # DW_LIB: tuning builds
 
-DW_ABI_VERSION = 3
+DW_ABI_VERSION = 4
 DW_OK, DW_EINVAL, DW_ENODEVICE, DW_ENOMEM, DW_EHIP, DW_ESTATE = 0, -1, -2, -3, -4, -5
 PRECISION = {"exact": 0, "fast": 1, "f64": 2}
 STATE_CURRENT, STATE_PREVIOUS = 0, 1
@@ -60,6 +60,8 @@ SIGNATURES = {
     "dw_get_params": (C.c_int, [_vp, C.POINTER(DwParams)]),
     "dw_last_error": (C.c_char_p, []),
     "dw_abi_version": (C.c_int, []),
+    "dw_pinned_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
+    "dw_pinned_free": (C.c_int, [C.c_void_p]),
     "dw_build_id": (C.c_char_p, []),
     "dw_upload_state_f64": (C.c_int, [_vp, _pd, _pd]),
     "dw_upload_state_f32": (C.c_int, [_vp, _pf, _pf, C.c_int]),

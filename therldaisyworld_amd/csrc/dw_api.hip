@@ -106,6 +106,8 @@ struct dw_handle {
     size_t scratch_bytes = 0;
     unsigned char* ep_buf = nullptr;  // device staging of dw_run_episode (schedules, tables, flags)
     size_t ep_bytes = 0;
+    double* mlp_w = nullptr;              // parameter sets of the last dw_run_episode_mlp call that passed them
+    int mlp_members = 0;
     unsigned char* ep_pinned = nullptr;   // page-locked host image of ep_buf (LDS-resident episode kernels: ONE upload
     size_t ep_pinned_bytes = 0;           // and ONE download per chunk instead of six pageable copies)
     double* reward_d = nullptr;       // [B][N]
@@ -840,6 +842,18 @@ extern "C" {
 const char* dw_last_error(void) { return g_err; }
 int dw_abi_version(void) { return DW_ABI_VERSION; }
 
+int dw_pinned_alloc(size_t bytes, void** out) {
+    NEED(out && bytes > 0, DW_EINVAL, "null argument");
+    int ndev = 0;
+    NEED(hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0, DW_ENODEVICE, "no HIP device");
+    HIPCHK(hipHostMalloc(out, bytes, hipHostMallocDefault));
+    return DW_OK;
+}
+int dw_pinned_free(void* p) {
+    if (p) HIPCHK(hipHostFree(p));
+    return DW_OK;
+}
+
 #ifndef DW_BUILD_ID
 #define DW_BUILD_ID "unknown"
 #endif
@@ -956,6 +970,7 @@ int dw_destroy(dw_handle* h) {
     (void)hipFree(h->reward_d); (void)hipFree(h->done_d);
     if (h->pinned) (void)hipHostFree(h->pinned);
     if (h->ep_pinned) (void)hipHostFree(h->ep_pinned);
+    (void)hipFree(h->mlp_w);
     (void)hipFree(h->snapL); (void)hipFree(h->snapD); (void)hipFree(h->snap_idx); (void)hipFree(h->snap_st);
     (void)hipFree(h->snapPL); (void)hipFree(h->snapPD);
     (void)hipFree(h->snap_stats);
@@ -1736,11 +1751,13 @@ int dw_policy_mlp_population(dw_handle* h, const double* params, int32_t n_membe
 int dw_run_episode_mlp(dw_handle* h, int32_t nsteps, const double* L_schedule, const double* params, int32_t n_members,
                        const int32_t* member_a, const int32_t* member_b, int32_t split, double L_init, double* reward,
                        uint8_t* done) {
-    NEED(h && L_schedule && params, DW_EINVAL, "null argument");
+    NEED(h && L_schedule, DW_EINVAL, "null argument");
     const dw_params& p = h->prm;
     HIPCHK(hipSetDevice(p.device));
     NEED(nsteps >= 1 && nsteps <= 4096, DW_EINVAL, "nsteps must be in 1..4096");
     NEED(n_members >= 1, DW_EINVAL, "n_members < 1");
+    NEED(params || (h->mlp_w && h->mlp_members == n_members), DW_ESTATE,
+         "params == NULL but no parameter sets of %d members are on the device", n_members);
     NEED(p.collision_mode == 0, DW_EINVAL, "collision_mode=1 is not implemented on the device");
     NEED(split >= 0 && split <= p.n_agents, DW_EINVAL, "split outside 0..n_agents");
     NEED(h->have_state && h->have_agents, DW_ESTATE, "no state / agents");
@@ -1754,17 +1771,25 @@ int dw_run_episode_mlp(dw_handle* h, int32_t nsteps, const double* L_schedule, c
     NEED(n_members == 1 || (member_a && member_b), DW_EINVAL, "several parameter sets need both member maps");
     auto up = [](size_t v) { return (v + 255) / 256 * 256; };
     const size_t wbytes = sizeof(double) * 1808 * (size_t)n_members;
-    const size_t o_w = 0, o_ma = up(o_w + wbytes), o_mb = up(o_ma + sizeof(int) * B), o_r = up(o_mb + sizeof(int) * B);
+    const size_t o_ma = 0, o_mb = up(o_ma + sizeof(int) * B), o_r = up(o_mb + sizeof(int) * B);
     const size_t o_d = up(o_r + sizeof(double) * K * bn), o_p32 = up(o_d + K * bn), o_ls = up(o_p32 + sizeof(PhysF32) * K);
     const size_t total = up(o_ls + sizeof(double) * K);
     if (int erc = ensure_ep_buf(h, total)) return erc;
-    const double* d_w = reinterpret_cast<const double*>(h->ep_buf + o_w);
+    if (params) {                                               // the sets stay on the device for later calls (params == NULL)
+        if (h->mlp_members != n_members) {
+            (void)hipFree(h->mlp_w);
+            h->mlp_w = nullptr; h->mlp_members = 0;
+            HIPCHK(hipMalloc(&h->mlp_w, wbytes));
+            h->mlp_members = n_members;
+        }
+    }
+    const double* d_w = h->mlp_w;
     const int* d_ma = member_a ? reinterpret_cast<const int*>(h->ep_buf + o_ma) : nullptr;
     const int* d_mb = member_b ? reinterpret_cast<const int*>(h->ep_buf + o_mb) : nullptr;
     double* d_r = reinterpret_cast<double*>(h->ep_buf + o_r);
     unsigned char* d_d = h->ep_buf + o_d;
     SyncOnExit guard(h->stream);                              // params / member maps are the caller's
-    HIPCHK(hipMemcpyAsync(h->ep_buf + o_w, params, wbytes, hipMemcpyHostToDevice, h->stream));
+    if (params) HIPCHK(hipMemcpyAsync(h->mlp_w, params, wbytes, hipMemcpyHostToDevice, h->stream));
     if (member_a) HIPCHK(hipMemcpyAsync(h->ep_buf + o_ma, member_a, sizeof(int) * B, hipMemcpyHostToDevice, h->stream));
     if (member_b) HIPCHK(hipMemcpyAsync(h->ep_buf + o_mb, member_b, sizeof(int) * B, hipMemcpyHostToDevice, h->stream));
     // Small worlds with a quantised state and a quantised retained previous state: the rest of the chunk in ONE
@@ -1772,7 +1797,10 @@ int dw_run_episode_mlp(dw_handle* h, int32_t nsteps, const double* L_schedule, c
     // previous state is the un-quantised upload - and for large worlds: one launch sequence per step.
     const int Cc = p.height * p.width;
     const int wpb = Cc <= 256 ? 4 : (Cc <= 1024 ? 2 : 1);
-    const size_t lds = episode_mlp_world_bytes(Cc, N) * wpb;
+    // H*W <= 256 with at most four agents (the ES trainers' own 16x16 x 4): one wave per world (dw_episode_wave.hpp)
+    const bool wave_kernel = Cc <= kEwMaxCells && 16 * N <= 64 && !std::getenv("DW_NO_EPISODE_WAVE");
+    const size_t lds = wave_kernel ? episode_wave_shared_bytes() + episode_mlp_wave_world_bytes(Cc, N) * 4
+                                   : episode_mlp_world_bytes(Cc, N) * wpb;
     const bool small = Cc <= 4096 && lds <= 160 * 1024 && p.precision != DW_PRECISION_F64 &&
                        !std::getenv("DW_NO_EPISODE_KERNEL");
     std::vector<PhysF32> p32;
@@ -1797,12 +1825,21 @@ int dw_run_episode_mlp(dw_handle* h, int32_t nsteps, const double* L_schedule, c
             io.reward = d_r + t * bn; io.done = d_d + t * bn;
             io.stats = stats; io.fixups = &stats[B].sum_l;
             const bool ex = p.precision == DW_PRECISION_EXACT;
-            auto kern = ex ? episode_mlp<true> : episode_mlp<false>;
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)lds));
-            hipLaunchKernelGGL(kern, dim3((unsigned)((B + wpb - 1) / wpb)), dim3(256), lds, h->stream, io, B, N, p.height,
-                               p.width, wpb, (int)Kr, p.obs_mask, p.agent_gamma, make_f64(p, L_schedule[t]), h->L_last,
-                               (int)split);
+            if (wave_kernel) {
+                auto kern = ex ? episode_mlp_wave<true> : episode_mlp_wave<false>;
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)lds));
+                const EpisodeMlpWaveArgs A{io, B, N, p.height, p.width, (int)Kr, p.obs_mask, (int)split, p.agent_gamma,
+                                           h->L_last, make_f64(p, L_schedule[t])};
+                hipLaunchKernelGGL(kern, dim3((unsigned)((B + 3) / 4)), dim3(256), lds, h->stream, A);
+            } else {
+                auto kern = ex ? episode_mlp<true> : episode_mlp<false>;
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)lds));
+                hipLaunchKernelGGL(kern, dim3((unsigned)((B + wpb - 1) / wpb)), dim3(256), lds, h->stream, io, B, N, p.height,
+                                   p.width, wpb, (int)Kr, p.obs_mask, p.agent_gamma, make_f64(p, L_schedule[t]), h->L_last,
+                                   (int)split);
+            }
             HIPCHK(hipGetLastError());
             h->stepped = true;
             h->L_last = L_schedule[K - 1];

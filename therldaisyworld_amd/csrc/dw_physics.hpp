@@ -91,6 +91,15 @@ __host__ __device__ inline double dw_permille_to_natural(double k) {
     return fma(fma(-q, 1000.0, k), r, q);
 }
 
+// k / 1000.0 for any double k holding an integer (a rounded temperature in milli-kelvin, a per-mille cover): the Newton
+// form above is the correctly rounded quotient for every |k| < 2^22 (checked exhaustively: tests/test_abi_and_host.py
+// compiles the loop); anything larger - non-physical parameters - takes the division.
+__device__ __forceinline__ double dw_div1000(double k) {
+    double q = dw_permille_to_natural(k);
+    if (__builtin_expect(!(fabs(k) < 4194304.0), 0)) q = k / 1000.0;
+    return q;
+}
+
 // Lean float64 evaluation for the exact mode's fix-up kernels: only the two new covers, and the
 // chain T_eff -> T -> T_x of the reference collapsed to T_x^4 = q2 (A_l - a_x) + q (A - A_l) +
 // S L (1 - A) / sigma (the intermediate fourth roots cancel; the difference to the staged form is a

@@ -54,6 +54,9 @@ class Engine:
         if getattr(self, "_h", None) is not None and self._h:
             self._lib.dw_destroy(self._h)
             self._h = C.c_void_p()
+        if getattr(self, "_pinned", None) is not None:          # (arrays handed out with reuse_buffers=True die with it)
+            self._lib.dw_pinned_free(self._pinned[0])
+            self._pinned = None
 
     def __del__(self):
         try:
@@ -308,24 +311,55 @@ class Engine:
             _ffi.ptr_u8(ok) if self.N else None))
         return (None if alive is None else alive.view(np.bool_)), ok.view(np.bool_)
 
-    def run_episode_mlp(self, L_schedule, params, member_a=None, member_b=None, split=None, L_init=0.75):
+    def run_episode_mlp(self, L_schedule, params, member_a=None, member_b=None, split=None, L_init=0.75,
+                        reuse_buffers=False, n_members=None):
         """K device-resident steps with MLP policies: agents [0, split) of world b use parameter set
         member_a[b], agents [split, N) member_b[b].  Returns (reward (K,B,N,1) float64, done (K,B,N,1) bool)
-        exactly as K calls of env.step would (ref step :486-492)."""
+        exactly as K calls of env.step would (ref step :486-492).
+
+        `params=None`: the parameter sets of the last call that passed them are still on the device and are used again
+        (pass `n_members`).  `reuse_buffers=True`: the returned arrays are views of page-locked buffers owned by this
+        engine (no staging copy on the way back) and are OVERWRITTEN by the next call with reuse_buffers=True - for
+        harnesses that consume a chunk's rewards before they run the next one."""
         Ls = np.ascontiguousarray(L_schedule, dtype=np.float64)
         K = Ls.shape[0]
-        w = np.ascontiguousarray(params, dtype=np.float64).reshape(-1, 1808)
+        if params is None:
+            if n_members is None:
+                raise ValueError("params=None needs n_members (the sets uploaded by an earlier call)")
+            w, nm = None, int(n_members)
+        else:
+            w = np.ascontiguousarray(params, dtype=np.float64).reshape(-1, 1808)
+            nm = w.shape[0]
         ma = None if member_a is None else np.ascontiguousarray(member_a, dtype=np.int32)
         mb = None if member_b is None else np.ascontiguousarray(member_b, dtype=np.int32)
         for m in (ma, mb):
             if m is not None and m.shape != (self.B,):
                 raise ValueError(f"member maps must have shape {(self.B,)}")
         split = self.N // 2 if split is None else int(split)
-        reward = np.zeros((K, self.B, self.N, 1))
-        done = np.zeros((K, self.B, self.N, 1), dtype=np.uint8)
-        self._check(self._lib.dw_run_episode_mlp(self._h, K, _ffi.ptr_d(Ls), _ffi.ptr_d(w), w.shape[0], _ffi.ptr_i(ma),
+        n = K * self.B * self.N
+        if reuse_buffers and n:
+            buf = self._pinned_block(9 * n)
+            reward = np.frombuffer(buf, dtype=np.float64, count=n).reshape(K, self.B, self.N, 1)
+            done = np.frombuffer(buf, dtype=np.uint8, count=n, offset=8 * n).reshape(K, self.B, self.N, 1)
+        else:
+            reward = np.empty((K, self.B, self.N, 1))              # (every element is written by the library; done: 0 / 1)
+            done = np.empty((K, self.B, self.N, 1), dtype=np.uint8)
+        self._check(self._lib.dw_run_episode_mlp(self._h, K, _ffi.ptr_d(Ls), _ffi.ptr_d(w), nm, _ffi.ptr_i(ma),
                                            _ffi.ptr_i(mb), split, float(L_init), _ffi.ptr_d(reward), _ffi.ptr_u8(done)))
-        return reward, done.astype(bool)
+        return reward, done.view(np.bool_)
+
+    def _pinned_block(self, nbytes):
+        """A page-locked host buffer of at least nbytes owned by this engine (grown geometrically, freed by close())."""
+        have = getattr(self, "_pinned", None)
+        if have is None or have[1] < nbytes:
+            if have is not None:
+                self._lib.dw_pinned_free(have[0])
+                self._pinned = None
+            size = max(int(nbytes), 2 * (have[1] if have else 0), 1 << 20)
+            ptr = C.c_void_p()
+            self._check(self._lib.dw_pinned_alloc(size, C.byref(ptr)))
+            self._pinned = (ptr, size, (C.c_ubyte * size).from_address(ptr.value))
+        return self._pinned[2]
 
     # -- plumbing -----------------------------------------------------------------------------
     def set_stream(self, hip_stream_ptr: int):

@@ -195,17 +195,24 @@ def _mlp_chunks(env, params, member_a, member_b, half, max_steps, chunk, after_c
     reference's loop leaves it."""
     eng = env._engine
     first, finished = True, False
+    n_members = np.asarray(params).reshape(-1, 1808).shape[0]
     while not finished and env.step_count < max_steps:
         K = 1 if first else min(int(chunk), max_steps - env.step_count)    # step 1 starts from the un-quantised state
         Ls = _luminosity_schedule(env, K)
         env._sync_to_device()
         if K > 1:
             eng.snapshot_save()
-        rewards, dones = eng.run_episode_mlp(Ls, params, member_a, member_b, half, env._L_pass)
-        executed, finished = after_chunk(rewards * (rewards > 0), dones)
+        # the parameter sets go up with the first chunk and stay on the device; rewards / done flags come back in the
+        # engine's page-locked buffers (consumed by after_chunk before the next chunk overwrites them)
+        rewards, dones = eng.run_episode_mlp(Ls, params if first else None, member_a, member_b, half, env._L_pass,
+                                             reuse_buffers=True, n_members=n_members)
+        # (the device already returns reward * (reward > 0), ref step :490: agent states are clipped to [0, 1], so the
+        # product is the state itself - a second pass over the (K,B,N,1) array would change no bit of it)
+        executed, finished = after_chunk(rewards, dones)
         if executed < K:
             eng.snapshot_restore()
-            eng.run_episode_mlp(Ls[:executed], params, member_a, member_b, half, env._L_pass)
+            eng.run_episode_mlp(Ls[:executed], None, member_a, member_b, half, env._L_pass, reuse_buffers=True,
+                                n_members=n_members)
         _advance_host_scalars(env, executed)
         first = False
 
@@ -218,7 +225,7 @@ def _fitness_chunk(acc, rewards, dones, half):
     K = rewards.shape[0]
     ended = np.nonzero(dones.reshape(K, -1).all(axis=1))[0]
     executed = int(ended[0]) + 1 if ended.size else K
-    alive = (1 - 1 * dones[:executed]).sum(axis=0)                    # integers: any order
+    alive = np.count_nonzero(~dones[:executed], axis=0)               # = sum(1 - done): integers, any order
     acc["done_at"] += alive
     acc["total_steps"] = acc["total_steps"] + alive
     means = [rewards[t][:, :half].mean() for t in range(executed)]    # the reference's call, step by step
@@ -241,7 +248,7 @@ def _population_chunk(acc, rewards, dones, half, worlds_per_member):
     none_left = np.nonzero(~(run_t & ~all_done).any(axis=1))[0]
     executed = int(none_left[0]) + 1 if none_left.size else K
     live = np.repeat(run_t[:executed], worlds_per_member, axis=1)[:, :, None, None]
-    alive = (live * (1 - 1 * dones[:executed])).sum(axis=0)                        # integers: any order
+    alive = np.count_nonzero(live & ~dones[:executed], axis=0)                     # = sum(live * (1 - done)): integers, any order
     acc["done_at"][...] += alive
     acc["total_steps"][...] += alive
     # one member's mean of one step = the reference's `reward[:, :half].mean()` on that member's block of worlds
