@@ -203,14 +203,21 @@ def selftest_spawn(args):
         time.sleep(3600)
     dist = ensemble.init_process_group("gloo", timeout_s=float(os.environ.get("DW_SELFTEST_DIST_TIMEOUT_S", "120"))) if world > 1 else None
     B = args.worlds or 3
+    # rehearsal of the DW_ENOMEM path of make_engine: one rank could only allocate half the worlds - every rank must
+    # end up with that rank's count (ensemble.agree_on_worlds, the call measure() makes)
+    B_here = max(1, B // 2) if os.environ.get("DW_SELFTEST_HALVE_RANK") == str(rank) else B
+    B = ensemble.agree_on_worlds(B_here) if dist is not None else B_here
     local = np.arange(B, dtype=np.int64) + rank * B
     if dist is not None:
         dist.barrier()
     elapsed = ensemble.max_over_ranks(0.001 * (rank + 1))
     allw = ensemble.gather_per_world(local) if dist is not None else local
+    group = ensemble.describe_group()
+    per_rank = ensemble.gather_scalars(float(rank + 1))
     if rank == 0:
         print(json.dumps({"selftest": "spawn", "n_gpus": world, "total_worlds": int(allw.shape[0]),
-                          "worlds": [int(x) for x in allw], "max_elapsed": elapsed}))
+                          "worlds": [int(x) for x in allw], "max_elapsed": elapsed, "worlds_per_rank": B,
+                          "rccl": group, "per_rank_value": per_rank}))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -274,11 +281,17 @@ def main():
         if worlds:
             B = worlds
         eng, B = make_engine(B, G, N, precision)
-        if dist is not None:                                # every rank must step the same number of worlds
-            B_all = int(ensemble.max_over_ranks(-B)) * -1
+        if dist is not None:
+            # every rank must step the same number of worlds: the smallest any rank could allocate.  This MIN is also
+            # the first collective after the allocation / initial draw (up to 128 GiB + 0.04 s per rank, more when a
+            # rank had to halve): behind it the 120 s collective timeout no longer spans that work.
+            eng.sync()
+            B_all = ensemble.agree_on_worlds(B)
             if B_all != B:
                 eng.close()
                 eng, B = make_engine(B_all, G, N, precision)
+                if ensemble.agree_on_worlds(B) != B:
+                    raise SystemExit(f"rank {rank}: could not allocate the {B_all} worlds the ranks agreed on")
         cells = B * G * G
         rng = np.random.RandomState(args.seed + rank)
 
@@ -340,6 +353,7 @@ def main():
         L = run(steps, L)
         ev_ms = eng.timer_stop()                        # HIP events on the kernel's stream (synchronises)
         torch.cuda.synchronize()
+        own_elapsed = time.perf_counter() - t0              # this rank's own K steps (before it waits for the others)
         if dist is not None:
             dist.barrier()
         elapsed = ensemble.max_over_ranks(time.perf_counter() - t0)
@@ -348,6 +362,7 @@ def main():
         info = eng.kernel_info()
         res = {"workload": workload, "desc": desc, "precision": precision, "B": B, "G": G, "N": N, "cells": cells,
                "value": cells * steps * n_gpus / elapsed, "ms_per_step": elapsed / steps * 1e3,
+               "rank_value": cells * steps / own_elapsed,
                "event_ms_per_step": ev_ms / steps, "fused_ms": fused_ms, "fused_launches": fused_n,
                "plane_elem_bytes": elem_bytes, "fixups": eng.last_fixup_count(), "kernel": info, "stats": stats,
                "preheat_s": preheat, "preheat_steps": pre_steps}
@@ -429,6 +444,8 @@ def main():
 
     m = measure(args.workload, args.precision, args.steps, args.warmup, args.preheat_s, args.worlds)
     all_stats = ensemble.gather_per_world(m["stats"]) if dist is not None else m["stats"]   # end-of-run gather (RCCL)
+    group = ensemble.describe_group()                       # backend, world size, RCCL version, ranks that answered
+    per_rank = ensemble.gather_scalars(m["rank_value"])     # each rank's own cell-updates/s over ITS elapsed time
     B, G, N = m["B"], m["G"], m["N"]
     out = {
         "metric": "cell-updates/sec (grid x batch), fused stencil+growth step",
@@ -454,6 +471,8 @@ def main():
                    "parallelism": f"ensemble shard x{n_gpus} (no data-path collective)"},
         "roofline": roofline(m),
         "preheat_s": round(m["preheat_s"], 3),
+        "rccl": group,
+        "per_rank_value": per_rank,
     }
     if WORKLOADS[args.workload][0] != B and not args.worlds:
         out["config"]["note"] = f"{WORKLOADS[args.workload][0]} worlds did not fit this device: measured {B}"

@@ -371,7 +371,8 @@ int dw_lifespan_download(dw_handle* h, int32_t* done_at /* [B] */, int32_t* agen
  * ones) run step PAIRS as one fused launch, with the agents' step in between recomputed around the
  * agents and patched into the result (csrc/dw_agents_fused.hpp) - same results, bit for bit.
  * Needs a quantised current state (take the first step of an episode with dw_step).
- * Afterwards the handle is exactly as after K calls of dw_step (previous state retained). */
+ * Afterwards the handle is exactly as after K calls of dw_step (previous state retained; the device action buffer
+ * - dw_download_actions - holds the resolved action codes of the LAST step, whichever kernel applied them). */
 enum { DW_POLICY_ZEROS = 2, DW_POLICY_TABLE = 3 };
 int dw_run_episode(dw_handle* h, int32_t nsteps, const double* L_schedule, int policy_mode,
                    const uint8_t* use_table, const int8_t* table, uint32_t threshold_k, uint8_t* world_alive,

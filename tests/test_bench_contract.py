@@ -46,6 +46,9 @@ def test_bench_line_follows_the_contract():
     for mode in d["modes"].values():
         assert mode["roofline"]["frac"] <= 1.0
     assert set(d["workloads"]["c2"]) == {"exact", "fast"}
+    # what ran: a single process has no collective backend; its own throughput is the whole job's
+    assert d["rccl"] == {"backend": None, "world_size": 1, "nccl_version": None, "ranks_reporting": [0]}
+    assert len(d["per_rank_value"]) == 1 and d["per_rank_value"][0] >= d["value"] * 0.999
 
 
 def test_bench_agent_workload_and_self_launched_ranks():
@@ -60,3 +63,5 @@ def test_bench_agent_workload_and_self_launched_ranks():
     assert p.returncode == 0, p.stderr[-3000:]
     d2 = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
     assert d2["n_gpus"] == 2 and d2["config"]["total_worlds"] == 128 and d2["cpu_baseline"] is None
+    assert d2["rccl"]["backend"] == "gloo" and d2["rccl"]["world_size"] == 2 and d2["rccl"]["ranks_reporting"] == [0, 1]
+    assert len(d2["per_rank_value"]) == 2 and sum(d2["per_rank_value"]) >= d2["value"] * 0.999

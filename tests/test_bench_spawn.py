@@ -92,3 +92,62 @@ def test_lifespan_sweep_launches_and_gathers_its_own_ranks():
     d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
     assert d["n_gpus"] == 2 and d["worlds"] == 10 and d["in_rank_order"]
     assert abs(d["wall_s"] - 0.02) < 1e-12
+
+
+def test_a_signal_to_the_parent_takes_every_rank_down(tmp_path):
+    """The ranks run in sessions of their own, so an outer `timeout` / scheduler / closed terminal that signals the parent
+    does not reach them by itself: the parent turns SIGTERM (and SIGHUP) into a clean stop of every rank.  Here rank 1
+    sleeps for an hour; the parent gets SIGTERM after the ranks are up; afterwards no process of the run is alive."""
+    import signal
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(DW_SELFTEST_HANG_RANK="1", DW_SELFTEST_DIST_TIMEOUT_S="600")
+    p = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--selftest-spawn", "--backend", "gloo", "--gpus", "2",
+                          "--rank-timeout-s", "600", "--rank-log-dir", str(tmp_path)], env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+
+    def rank_pids():
+        me, out = str(p.pid), []
+        for d in os.listdir("/proc"):
+            if d.isdigit():
+                try:
+                    with open(f"/proc/{d}/stat") as f:
+                        fields = f.read().rsplit(")", 1)[1].split()
+                    if fields[1] == me:                       # ppid
+                        out.append(int(d))
+                except OSError:
+                    pass
+        return out
+
+    t_end = time.monotonic() + 60
+    kids = []
+    while time.monotonic() < t_end and len(kids) < 2:         # both ranks started
+        kids = rank_pids()
+        time.sleep(0.1)
+    assert len(kids) == 2, kids
+    time.sleep(1.0)
+    p.send_signal(signal.SIGTERM)
+    try:
+        p.wait(timeout=30)
+    except subprocess.TimeoutExpired:
+        p.kill()
+        raise AssertionError("the parent did not exit after SIGTERM")
+    assert p.returncode != 0
+    t_end = time.monotonic() + 10
+    while time.monotonic() < t_end and any(os.path.exists(f"/proc/{k}") for k in kids):
+        time.sleep(0.1)
+    assert not [k for k in kids if os.path.exists(f"/proc/{k}")], "a rank survived its parent's SIGTERM"
+
+
+def test_a_rank_that_could_only_allocate_half_the_worlds_sets_the_count_for_all():
+    """bench.py `make_engine` halves a rank's world count while its device cannot hold the state (DW_ENOMEM); weak
+    scaling then needs EVERY rank to step that smaller count (ensemble.agree_on_worlds: one MIN all-reduce, also the
+    first collective after the allocations).  The line also says which backend ran, with how many ranks, and lists
+    every rank's own throughput."""
+    d = _run(["--gpus", "2", "--worlds", "8"], {"DW_SELFTEST_HALVE_RANK": "1"})
+    assert d["worlds_per_rank"] == 4 and d["total_worlds"] == 8
+    assert d["worlds"] == [0, 1, 2, 3, 4, 5, 6, 7]
+    assert d["rccl"]["backend"] == "gloo" and d["rccl"]["world_size"] == 2 and d["rccl"]["ranks_reporting"] == [0, 1]
+    assert d["per_rank_value"] == [1.0, 2.0]
+    d1 = _run(["--gpus", "1", "--worlds", "4"])
+    assert d1["rccl"] == {"backend": None, "world_size": 1, "nccl_version": None, "ranks_reporting": [0]}

@@ -946,10 +946,11 @@ def test_run_episode_matches_stepwise_engine(amd, B, H, W):
                 alive[t] = eng.reduce()["max_k"] > 5
                 ok[t] = ~eng.reward_done()[1][..., 0]
         outs.append((alive, ok, eng.download_planes(), eng.download_planes(1), eng.download_agents(), eng.reduce(),
-                     eng.download_grid(), eng.get_obs()))
+                     eng.download_grid(), eng.get_obs(), eng.download_actions()))
         eng.close()
     a, b = outs
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert np.array_equal(a[8], b[8])                         # the action buffer: the LAST step's codes either way
     for i in (2, 3, 4):
         assert np.array_equal(a[i][0], b[i][0]) and np.array_equal(a[i][1], b[i][1])
     for f in ("max_k", "sum_light_k", "sum_dark_k"):

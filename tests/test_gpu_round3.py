@@ -77,8 +77,8 @@ def test_exact_mode_sweeps_its_queue_before_it_overflows(amd, monkeypatch, fuse)
     strip pair) recomputed its whole strip in float64 - the launch took 30x as long.  Now the wave sweeps its queue
     (float64 re-evaluation, patches) whenever it is half full, inside the row loop: the same results bit for bit at
     any strip height, and 1.23x the time (measured) even with the queue cut to a sixth (single-step kernel, whose deep
-    load pipeline drains at every sweep: 1.28-1.38x; with its real capacity it never sweeps mid-strip).  Asserted with
-    room for a noisy box (<= 1.7x / 2x): the property is 'no cliff', the exact ratios are in DESIGN.md 7.0."""
+    load pipeline drains at every sweep: 1.28-1.38x; with its real capacity it never sweeps mid-strip).  The test asserts
+    the mechanism (the float64 cell count) and only a loose 'no cliff' bound on time; the ratios are in DESIGN.md 7.0."""
     B, G, warm, timed = 1024, 256, 220, 64
 
     def run(env):
@@ -89,9 +89,11 @@ def test_exact_mode_sweeps_its_queue_before_it_overflows(amd, monkeypatch, fuse)
             monkeypatch.delenv(k)
         eng.init_random(42)
         L = eng.step_n(warm, 0.75, 0.75 / 512, 0.75, 1.5)
-        eng.timer_start()
-        eng.step_n(timed, L, 0.0, 0.75, 1.5)
-        ms = eng.timer_stop()
+        ms = float("inf")
+        for _ in range(3):                                       # the best of three: one throttled run must not decide
+            eng.timer_start()
+            L = eng.step_n(timed, L, 0.0, 0.75, 1.5)
+            ms = min(ms, eng.timer_stop())
         planes = eng.download_planes()
         fix = eng.last_fixup_count()
         eng.close()
@@ -101,8 +103,11 @@ def test_exact_mode_sweeps_its_queue_before_it_overflows(amd, monkeypatch, fuse)
     ms_ref, ref, fix_ref = run(base)
     ms_cap, got, fix_cap = run(dict(base, DW_TEST_QUEUE_CAP="40"))
     assert np.array_equal(_k(ref[0]), _k(got[0])) and np.array_equal(_k(ref[1]), _k(got[1]))
-    assert fix_ref == fix_cap > 0                                # the same cells went through float64
-    assert ms_cap <= (1.7 if fuse else 2.0) * ms_ref, (ms_ref, ms_cap)
+    # THE MECHANISM: the same cells went through float64, one by one - a strip that falls back to whole-strip float64
+    # does not count its cells, so an overflow anywhere would show here
+    assert fix_ref == fix_cap > 0
+    # ... and no cliff in time (round 2: 30x; measured 1.23-1.38x; a loose bound on the best of three runs: shared boxes)
+    assert ms_cap <= 5.0 * ms_ref, (ms_ref, ms_cap)
 
 
 def test_tall_strips_do_not_overflow_any_more(amd, monkeypatch):
@@ -118,17 +123,21 @@ def test_tall_strips_do_not_overflow_any_more(amd, monkeypatch):
             monkeypatch.delenv(k)
         eng.init_random(42)
         L = eng.step_n(360, 0.75, 0.75 / 512, 0.75, 1.5)          # around the tie-density peak of the ramp
-        eng.timer_start()
-        eng.step_n(64, L, 0.0, 0.75, 1.5)
-        ms = eng.timer_stop()
+        ms = float("inf")
+        for _ in range(3):
+            eng.timer_start()
+            L = eng.step_n(64, L, 0.0, 0.75, 1.5)
+            ms = min(ms, eng.timer_stop())
         planes = eng.download_planes()
+        fix = eng.last_fixup_count()
         eng.close()
-        return ms, planes
+        return ms, planes, fix
 
-    ms64, p64 = run({})
-    ms128, p128 = run({"DW_STRIP_ROWS": "128"})
+    ms64, p64, fix64 = run({})
+    ms128, p128, fix128 = run({"DW_STRIP_ROWS": "128"})
     assert np.array_equal(_k(p64[0]), _k(p128[0])) and np.array_equal(_k(p64[1]), _k(p128[1]))
-    assert ms128 <= 1.7 * ms64, (ms64, ms128)                    # (round 2: 4x; not faster: fewer, longer strips - measured 1.14x)
+    assert fix64 == fix128 > 0                                   # no whole-strip fallback: every near-tie cell counted one by one
+    assert ms128 <= 5.0 * ms64, (ms64, ms128)                    # (round 2: 4x slower; measured now 1.14x; loose: shared boxes)
 
 
 # ---------------------------------------------------------------------------------------------

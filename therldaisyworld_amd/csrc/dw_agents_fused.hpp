@@ -68,6 +68,9 @@ struct LookaheadArgs {
     // fused launch (two launches per pair instead of four).  Null: the caller runs them as kernels of their own.
     const signed char* code_next;                // [B][N] for step t+2, or null
     unsigned char* agent_ok_next;                // [B][N] reward >= 0.1 after step t+2's update_agents
+    int* action_out;                             // [B][N] the handle's action buffer: the action codes of the LAST
+                                                 // update_agents this kernel applies (step t+2's if code_next, else t+1's),
+                                                 // so that dw_download_actions after a chunk returns the last step's actions
     // per-step "biosphere alive" flags (max cover > thr/1000) of the two steps, or null; pstats[2b], [2b+1]:
     // the fused launch's exact step-1 maximum and its count of certain step-2 row groups above thr
     unsigned char* alive_t; unsigned char* alive_t1;
@@ -139,6 +142,7 @@ __global__ __launch_bounds__(64) void agents_lookahead_patch(LookaheadArgs A) {
             a = 4 + best;
         }
         s_act[lane] = a;
+        if (A.action_out && !A.code_next) A.action_out[an] = a;
     }
     if (lane == 0) s_ng = 0;
     __syncthreads();
@@ -281,6 +285,7 @@ __global__ __launch_bounds__(64) void agents_lookahead_patch(LookaheadArgs A) {
                 a = 4 + best;
             }
             s_act[lane] = a;
+            if (A.action_out) A.action_out[an] = a;
         }
         __syncthreads();
         if (lane == 0) {

@@ -1007,19 +1007,21 @@ int dw_get_params(const dw_handle* h, dw_params* out) {
 // ---- state in / out ---------------------------------------------------------------------------
 
 // reductions of the current state, whatever its format (after uploads / init, so that dw_reduce is always valid)
+static int clear_stats(dw_handle* h) {
+    for (int i = 0; i < 2; ++i) HIPCHK(hipMemsetAsync(h->stats2[i], 0, h->stats_bytes, h->stream));
+    return DW_OK;
+}
 static int refresh_stats(dw_handle* h) {
     const dw_params& p = h->prm;
-    for (int i = 0; i < 2; ++i) HIPCHK(hipMemsetAsync(h->stats2[i], 0, h->stats_bytes, h->stream));
-    const dim3 g((unsigned)((p.height * p.width + kStatsChunk - 1) / kStatsChunk), (unsigned)p.batch);
+    if (int rc = clear_stats(h)) return rc;
+    const int n = p.height * p.width;
+    const dim3 g((unsigned)((n + kInitChunk - 1) / kInitChunk), (unsigned)p.batch);
     if (h->unq != OWN_CUR)
-        hipLaunchKernelGGL((stats_only<plane_t>), g, dim3(256), 0, h->stream, h->L16[h->cur], h->D16[h->cur], p.height,
-                           p.width, h->stats2[h->sp]);
+        hipLaunchKernelGGL((stats_only<plane_t>), g, dim3(256), 0, h->stream, h->L16[h->cur], h->D16[h->cur], n, h->stats2[h->sp]);
     else if (h->unq_kind == UNQ_F64)
-        hipLaunchKernelGGL((stats_only<double>), g, dim3(256), 0, h->stream, h->L64, h->D64, p.height, p.width,
-                           h->stats2[h->sp]);
+        hipLaunchKernelGGL((stats_only<double>), g, dim3(256), 0, h->stream, h->L64, h->D64, n, h->stats2[h->sp]);
     else
-        hipLaunchKernelGGL((stats_only<float>), g, dim3(256), 0, h->stream, h->U32L, h->U32D, p.height, p.width,
-                           h->stats2[h->sp]);
+        hipLaunchKernelGGL((stats_only<float>), g, dim3(256), 0, h->stream, h->U32L, h->U32D, n, h->stats2[h->sp]);
     HIPCHK(hipGetLastError());
     return DW_OK;
 }
@@ -1118,10 +1120,13 @@ int dw_init_random(dw_handle* h, uint64_t seed) {
     HIPCHK(hipSetDevice(p.device));
     int rc = ensure_u32(h);                     // the synthetic initial state is un-quantised like the reference's
     if (rc) return rc;
-    const dim3 g((unsigned)((p.height * p.width + 255) / 256), (unsigned)p.batch);
-    hipLaunchKernelGGL(init_random_cells, g, dim3(256), 0, h->stream, h->U32L, h->U32D, p.height,
-                       p.width, (long long)p.world_offset, (unsigned long long)seed, (float)p.light_proportion,
-                       (float)p.dark_proportion, (float)p.initial_al, (float)p.initial_ad);
+    // the draw reduces its own values into the per-world statistics (no second pass over the planes)
+    if (int crc = clear_stats(h)) return crc;
+    const int ncell = p.height * p.width;
+    const dim3 g((unsigned)((ncell + kInitChunk - 1) / kInitChunk), (unsigned)p.batch);
+    hipLaunchKernelGGL((init_random_cells<float>), g, dim3(256), 0, h->stream, h->U32L, h->U32D, ncell,
+                       (long long)p.world_offset, (unsigned long long)seed, (float)p.light_proportion,
+                       (float)p.dark_proportion, (float)p.initial_al, (float)p.initial_ad, h->stats2[h->sp]);
     HIPCHK(hipGetLastError());
     if (p.n_agents) {
         const int bn = p.batch * p.n_agents;
@@ -1136,17 +1141,19 @@ int dw_init_random(dw_handle* h, uint64_t seed) {
     h->have_state = true;
     h->stepped = false;
     h->snap_valid = false;
-    return refresh_stats(h);
+    return DW_OK;                               // (statistics: reduced by the draw itself)
 }
 
 int dw_init_random_quantised(dw_handle* h, uint64_t seed) {
     NEED(h, DW_EINVAL, "null handle");
     const dw_params& p = h->prm;
     HIPCHK(hipSetDevice(p.device));
-    const dim3 g((unsigned)((p.height * p.width + 255) / 256), (unsigned)p.batch);
-    hipLaunchKernelGGL(init_random_cells_q, g, dim3(256), 0, h->stream, h->L16[h->cur], h->D16[h->cur], p.height,
-                       p.width, (long long)p.world_offset, (unsigned long long)seed, (float)p.light_proportion,
-                       (float)p.dark_proportion, (float)p.initial_al, (float)p.initial_ad);
+    if (int crc = clear_stats(h)) return crc;
+    const int ncell = p.height * p.width;
+    const dim3 g((unsigned)((ncell + kInitChunk - 1) / kInitChunk), (unsigned)p.batch);
+    hipLaunchKernelGGL((init_random_cells<plane_t>), g, dim3(256), 0, h->stream, h->L16[h->cur], h->D16[h->cur], ncell,
+                       (long long)p.world_offset, (unsigned long long)seed, (float)p.light_proportion,
+                       (float)p.dark_proportion, (float)p.initial_al, (float)p.initial_ad, h->stats2[h->sp]);
     HIPCHK(hipGetLastError());
     if (p.n_agents) {
         const int bn = p.batch * p.n_agents;
@@ -1161,7 +1168,7 @@ int dw_init_random_quantised(dw_handle* h, uint64_t seed) {
     h->stepped = false;
     h->snap_valid = false;
     release_unquantised(h);
-    return refresh_stats(h);
+    return DW_OK;                               // (statistics: reduced by the draw itself)
 }
 
 int dw_download_planes(dw_handle* h, int which, double* light, double* dark) {
@@ -1824,6 +1831,7 @@ int dw_run_episode_mlp(dw_handle* h, int32_t nsteps, const double* L_schedule, c
             io.weights = d_w; io.member_a = d_ma; io.member_b = d_mb;
             io.reward = d_r + t * bn; io.done = d_d + t * bn;
             io.stats = stats; io.fixups = &stats[B].sum_l;
+            io.action = h->action;
             const bool ex = p.precision == DW_PRECISION_EXACT;
             if (wave_kernel) {
                 auto kern = ex ? episode_mlp_wave<true> : episode_mlp_wave<false>;
@@ -1989,6 +1997,7 @@ static int run_episode_stepwise(dw_handle* h, int32_t nsteps, const double* L_sc
             A.agent_ok = h->ep_buf + o_ok + (t + 1) * bn;
             A.code_next = nullptr;
             A.agent_ok_next = nullptr;
+            A.action_out = h->action;
             if (t + 2 < K && !no_preapply) {                   // the chunk continues with step t+2
                 const bool tab3 = policy_mode == DW_POLICY_TABLE || (use_table && use_table[t + 2]);
                 A.code_next = reinterpret_cast<const signed char*>(tab3 ? h->ep_buf + o_tab + (t + 2) * bn : h->ep_buf + o_code);
@@ -2104,6 +2113,7 @@ static int run_episode_impl(dw_handle* h, int32_t nsteps, const double* L_schedu
     io.agent_ok = h->ep_buf + o_ok;
     io.stats = stats;
     io.fixups = &stats[B].sum_l;
+    io.action = (N > 0 && policy_mode != kPolicySkipAgents) ? h->action : nullptr;
     const PhysF64 P64 = make_f64(p, L_schedule[0]);
     const dim3 grid((unsigned)((B + wpb - 1) / wpb));
     const bool ex = p.precision == DW_PRECISION_EXACT;

@@ -38,6 +38,7 @@ struct EpisodeIO {
     unsigned char* agent_ok;        // [K][B][N] out
     StatsDev* stats;                // [B] out: reductions after the last step
     unsigned long long* fixups;     // out: float64 re-evaluations of the last step (summed)
+    int* action;                    // [B][N] out: the LAST step's action codes (the handle's action buffer), or null
 };
 
 // float64 value of cell c of an LDS-resident world (exact mode's re-evaluation of a near-tie cell)
@@ -250,6 +251,7 @@ __global__ __launch_bounds__(256) void episode_small(EpisodeIO io, int B, int N,
                     a = 4 + best;
                 }
                 act[n] = a;
+                if (t == K - 1 && io.action) io.action[(size_t)b * N + n] = a;
             }
         }
         __syncthreads();
@@ -324,6 +326,7 @@ struct EpisodeMlpIO {
     unsigned char* done;            // [K][B][N] out
     StatsDev* stats;                // [B] out: reductions after the last step
     unsigned long long* fixups;
+    int* action;                    // [B][N] out: the LAST step's action codes (the handle's action buffer), or null
 };
 
 __host__ __device__ constexpr size_t episode_mlp_world_bytes(int C, int N) {
@@ -458,6 +461,7 @@ __global__ __launch_bounds__(256) void episode_mlp(EpisodeMlpIO io, int B, int N
                     if (o > bestv) { best = k; bestv = o; }    // first maximum, as np.argmax
                 }
                 act[n] = best;
+                if (t == K - 1 && io.action) io.action[(size_t)b * N + n] = best;
             }
         }
         __syncthreads();

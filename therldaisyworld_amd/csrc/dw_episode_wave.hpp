@@ -265,6 +265,7 @@ __global__ __launch_bounds__(256) void episode_wave(EpisodeWaveArgs A) {
                 { const bool bt = argmin ? v2 < bestv : v2 > bestv; best = bt ? 2 : best; bestv = bt ? v2 : bestv; }
                 { const bool bt = argmin ? v3 < bestv : v3 > bestv; best = bt ? 3 : best; }
                 const int a = greedy ? 4 + best : (from_table ? tab : 0);
+                if (t0 + ts == K - 1 && is_agent && io.action) io.action[(size_t)b * N + lane] = a;
                 ew_update_agents(a, R, is_agent, lane, N, W, agent_gamma, ast, ar, ac, pc);
             }
             // ---- forward (ref :434-461) ----
@@ -522,6 +523,7 @@ __global__ __launch_bounds__(256) void episode_mlp_wave(EpisodeMlpWaveArgs A) {
             }
             // ---- update_agents; the step's reward / done (ref step :486-492) ----
             ew_update_agents(act, R, is_agent, lane, N, W, agent_gamma, ast, ar, ac, pc);
+            if (t0 + ts == K - 1 && is_agent && io.action) io.action[(size_t)b * N + lane] = act;
             if (is_agent) {
                 sSt[lane] = ast; sIdx[2 * lane] = ar; sIdx[2 * lane + 1] = ac;
                 const double rw = ast * (ast > 0.0 ? 1.0 : 0.0);

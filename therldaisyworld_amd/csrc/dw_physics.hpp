@@ -231,7 +231,9 @@ template <> struct Lanes<float> {
     static __device__ __forceinline__ float abs(float v) { return __builtin_fabsf(v); }
     static __device__ __forceinline__ float clip(float v) { return fminf(fmaxf(v, 0.0f), 1000.0f); }
     static __device__ __forceinline__ float get(float v, int) { return v; }
-    static __device__ __forceinline__ void gt(float a, float b, bool* out) { out[0] = a > b; }
+    // "a > b or unordered": a NaN anywhere in the float32 chain must flag the cell (float64 decides), exactly as the
+    // lane-mask form below does - every kernel variant then agrees on NaN inputs and non-physical parameters
+    static __device__ __forceinline__ void gt(float a, float b, bool* out) { out[0] = !(a <= b); }
     // the same comparison as the wave's 64-bit lane mask (v_cmp writes exactly that into a scalar pair): the hot
     // kernels combine, test and count tie flags on the scalar unit, with no per-lane booleans in between
     static __device__ __forceinline__ void gtm(float a, float b, unsigned long long* out) {
@@ -254,7 +256,7 @@ template <> struct Lanes<dw_f32x2> {
         return T{fminf(fmaxf(v.x, 0.0f), 1000.0f), fminf(fmaxf(v.y, 0.0f), 1000.0f)};
     }
     static __device__ __forceinline__ float get(T v, int i) { return i == 0 ? v.x : v.y; }
-    static __device__ __forceinline__ void gt(T a, T b, bool* out) { out[0] = a.x > b.x; out[1] = a.y > b.y; }
+    static __device__ __forceinline__ void gt(T a, T b, bool* out) { out[0] = !(a.x <= b.x); out[1] = !(a.y <= b.y); }
     static __device__ __forceinline__ void gtm(T a, T b, unsigned long long* out) {
         out[0] = __builtin_amdgcn_fcmpf(a.x, b.x, 10 /* FCMP_UGT */);
         out[1] = __builtin_amdgcn_fcmpf(a.y, b.y, 10);

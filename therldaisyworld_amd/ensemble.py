@@ -87,6 +87,12 @@ def launch_ranks(script: str, argv, n_ranks: int, rank_timeout_s: float = 300.0,
     * a rendezvous port that was taken between its selection and rank 0's bind ("address already in use") gets
       ONE fresh attempt on another port.
 
+    * the ranks run in sessions of their own, so a signal to the parent's process group does not reach them: while
+      they run, SIGTERM / SIGHUP to the parent (an outer `timeout`, a scheduler, a closed terminal) are turned into
+      SystemExit, so that the `finally` below stops every rank; and every rank asks the kernel to send it SIGKILL when
+      its parent dies (PR_SET_PDEATHSIG, set between fork and exec - before anything touches a GPU) for the cases no
+      handler sees (SIGKILL of the parent).
+
     The parent never imports torch or the HIP library and nothing is re-exec'd: children are fresh processes,
     and only those are ever signalled (by the exact process group each was started in)."""
     import signal
@@ -96,10 +102,27 @@ def launch_ranks(script: str, argv, n_ranks: int, rank_timeout_s: float = 300.0,
     import tempfile
     import time
 
+    import threading
+
     own_dir = log_dir is None
     if own_dir:
         log_dir = tempfile.mkdtemp(prefix="dw_ranks_")
     os.makedirs(log_dir, exist_ok=True)
+
+    def die_with_parent():                                      # runs in the child between fork and exec
+        try:
+            import ctypes
+            ctypes.CDLL(None, use_errno=True).prctl(1, int(signal.SIGKILL), 0, 0, 0)     # PR_SET_PDEATHSIG
+        except Exception:
+            pass
+
+    def on_signal(signum, frame):
+        raise SystemExit(128 + signum)
+
+    restore = {}
+    if threading.current_thread() is threading.main_thread():
+        for sig in (signal.SIGTERM, signal.SIGHUP):
+            restore[sig] = signal.signal(sig, on_signal)
 
     def stop(procs):
         for p in procs:
@@ -133,7 +156,7 @@ def launch_ranks(script: str, argv, n_ranks: int, rank_timeout_s: float = 300.0,
             err = open(os.path.join(log_dir, f"rank{r}{tag}.err"), "wb")
             files += [out, err]
             procs.append(subprocess.Popen([sys.executable, os.path.abspath(script), *argv], env=env, stdout=out,
-                                          stderr=err, start_new_session=True))
+                                          stderr=err, start_new_session=True, preexec_fn=die_with_parent))
         deadline = time.monotonic() + float(rank_timeout_s)
         code, why = 0, ""
         try:
@@ -158,10 +181,14 @@ def launch_ranks(script: str, argv, n_ranks: int, rank_timeout_s: float = 300.0,
         return code, why, [p.returncode for p in procs]
 
     tag = ""
-    code, why, rcs = attempt(tag)
-    if code == 1 and any("ddress already in use" in _tail(os.path.join(log_dir, f"rank{r}.err")) for r in range(n_ranks)):
-        tag = ".retry"
+    try:
         code, why, rcs = attempt(tag)
+        if code == 1 and any("ddress already in use" in _tail(os.path.join(log_dir, f"rank{r}.err")) for r in range(n_ranks)):
+            tag = ".retry"
+            code, why, rcs = attempt(tag)
+    finally:
+        for sig, old in restore.items():
+            signal.signal(sig, old)
     sys.stdout.write(_tail(os.path.join(log_dir, f"rank0{tag}.out"), 1 << 22))
     sys.stdout.flush()
     if code:
@@ -219,3 +246,49 @@ def max_over_ranks(value: float, device=None) -> float:
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def agree_on_worlds(worlds_here: int, device=None) -> int:
+    """Weak scaling needs every rank to step the SAME number of worlds: the smallest any rank could allocate (a rank whose
+    device could not hold the requested ensemble halves its count, bench.py `make_engine`).  One MIN all-reduce; it is
+    also the first collective after the ranks' allocations and initial draws, i.e. the barrier behind which the
+    collective timeout no longer spans that work."""
+    return -int(max_over_ranks(-float(worlds_here), device))
+
+
+def describe_group(device=None) -> dict:
+    """What actually ran, for the bench line: backend, world size, the collective library's version and - from an
+    all-gather of the rank ids over that backend - which ranks answered.  Single process: backend None."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return {"backend": None, "world_size": 1, "nccl_version": None, "ranks_reporting": [0]}
+    backend = dist.get_backend()
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else "cpu"
+    mine = torch.tensor([dist.get_rank()], dtype=torch.int64, device=device)
+    got = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(got, mine)
+    version = None
+    if backend == "nccl":
+        try:
+            version = ".".join(str(v) for v in torch.cuda.nccl.version())     # RCCL reports itself through this call
+        except Exception:
+            version = None
+    return {"backend": backend, "world_size": dist.get_world_size(), "nccl_version": version,
+            "ranks_reporting": sorted(int(t.item()) for t in got)}
+
+
+def gather_scalars(value: float, device=None) -> list:
+    """One float per rank, in rank order, on every rank."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [float(value)]
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else "cpu"
+    mine = torch.tensor([value], dtype=torch.float64, device=device)
+    got = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(got, mine)
+    return [float(t.item()) for t in got]
+
