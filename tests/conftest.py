@@ -29,3 +29,10 @@ def golden():
     def load(name):
         return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
     return load
+
+
+@pytest.fixture(autouse=True)
+def _library_test_hooks(monkeypatch):
+    """The library honours its DW_TEST_* hooks (shrunk repair queues, injected allocation failures, forced fallback
+    paths) only when DW_TEST_HOOKS is set, and reads every switch once, when a handle is created: the tests set it."""
+    monkeypatch.setenv("DW_TEST_HOOKS", "1")

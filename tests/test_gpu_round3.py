@@ -144,14 +144,17 @@ def test_tall_strips_do_not_overflow_any_more(amd, monkeypatch):
 # the first exact step from an un-quantised state is float32 + a tie bound, float64 for flagged cells only
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("fmt", ["f64", "f32", "philox"])
-@pytest.mark.parametrize("shape", [(3, 200, 260), (2, 512, 512), (5, 64, 64), (3, 100, 1024), (70, 7, 256)])
-def test_first_exact_step_from_unquantised_state_is_bit_exact(amd, fmt, shape):
+@pytest.mark.parametrize("shape", [(3, 200, 260), (2, 512, 512), (5, 64, 64), (3, 100, 1024), (70, 7, 256),
+                                   (64, 64, 64), (1000, 8, 8), (3, 130, 520), (40, 24, 96)])   # round 4: packed / general halo
+def test_first_exact_step_from_unquantised_state_is_bit_exact(amd, monkeypatch, fmt, shape):
     """The reference's initial grid is not rounded (ref :285-324): the first step reads float64 natural covers (or,
     for the synthetic ensembles, float32 per-mille ones).  It now runs in float32 with the error bound for
     non-integer inputs and re-evaluates only the flagged cells in float64: results identical to the float64
     oracle on the same state, for all three upload formats, several luminosities, and a small flagged fraction.
-    Widths that are multiples of 256 take the wave-strip kernel (step_first_stream), the others step_generic."""
+    Every shape the wave-strip kernels take runs step_first_stream (round 4: also the general-halo widths and the packed
+    mode of narrow worlds, here with the packing threshold lowered to the test's small ensembles), the others step_generic."""
     from oracle import c_oracle
+    monkeypatch.setenv("DW_PACK_MIN_STRIPS", "1")
     B, H, W = shape
     rng = np.random.RandomState(B * H + W)
     for L in (0.75, 1.02, 1.4):
@@ -197,13 +200,14 @@ def test_first_exact_step_dense_unquantised_state(amd):
 
 
 @pytest.mark.parametrize("fmt", ["f64", "f32"])
-@pytest.mark.parametrize("shape", [(2, 256, 256), (2, 130, 768)])
+@pytest.mark.parametrize("shape", [(2, 256, 256), (2, 130, 768), (3, 130, 520), (37, 64, 64), (70, 24, 96), (200, 8, 8)])
 def test_first_step_kernels_agree_and_the_flag_list_sweeps(amd, monkeypatch, fmt, shape):
     """The wave-strip first-step kernel against the one-thread-per-cell kernel (DW_FIRST_GENERIC=1) on the same
     un-rounded state: float32-only mode bit-identical (the same operations in the same order); exact mode identical
     to the float64 oracle also when a widened bracket (DW_TEST_FIRST_SLACK) flags a large share of the cells, so
     that every wave sweeps its list of flagged cells several times inside its strip."""
     from oracle import c_oracle
+    monkeypatch.setenv("DW_PACK_MIN_STRIPS", "1")               # (the narrow shapes: packed wave-strip mode)
     B, H, W = shape
     rng = np.random.RandomState(H + W)
     light = rng.rand(B, H, W) * (rng.rand(B, H, W) > 0.4)

@@ -119,13 +119,14 @@ def test_fused_float32_kernels_instruction_budget(asm):
 
 
 def test_first_step_stream_kernels_are_packed_and_spill_free(asm):
-    """step_first_stream (the first step of an episode on widths that are multiples of 256): packed float32 in its row
-    loop, no scratch anywhere in the kernel, float32-only variants at >= 4 waves/SIMD, the bounded exact ones at >= 3."""
+    """step_first_stream (the first step of an episode on every shape the wave-strip kernels take): packed float32 in its
+    row loop, no scratch anywhere in the kernel, float32-only variants at >= 4 waves/SIMD, the bounded exact ones at >= 3."""
     ks = {n: v for n, v in _kernels(asm).items() if "step_first_stream" in n}
-    assert len(ks) == 8                                       # float / double input x float32-only / bounded x HALO 0 / 1
+    assert len(ks) == 16                                      # float / double input x float32-only / bounded x HALO 0 .. 3
     for name, (info, body) in ks.items():
         assert not re.search(r"\tscratch_", body), name
-        bounded = "Li3E" in name
+        prec, halo = (int(x) for x in re.search(r"step_first_streamI[fd]Li(\d)ELi(\d)E", name).groups())
+        bounded = prec == 3
         assert info["Occupancy"] >= (3 if bounded else 4), (name, info["NumVgprs"])
         loop = _hot_loop(body)
         npk = sum(1 for ln in loop if ln.startswith("\tv_pk_"))

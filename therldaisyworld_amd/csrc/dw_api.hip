@@ -59,6 +59,46 @@ static int fail(int code, const char* fmt, ...) {
 enum UnqKind { UNQ_F64 = 1, UNQ_F32 = 2 };
 enum UnqOwner { OWN_NONE = 0, OWN_CUR = 1, OWN_PREV = 2 };
 
+// Experiment and test switches (environment variables), read ONCE per handle at dw_create - a handle behaves the same for
+// its whole life whatever the environment does afterwards - and reported by dw_kernel_info when any is set.  None changes
+// results.  The DW_TEST_* hooks (shrunk queues, injected allocation failures, forced fallbacks) are honoured only when
+// DW_TEST_HOOKS is set as well: a stray variable in a user's environment cannot inject failures.
+struct Switches {
+    bool no_sym = false, no_pack = false, no_fuse = false, no_ring = false, no_episode_kernel = false,
+         no_episode_wave = false, no_agent_fuse = false, no_agent_preapply = false, first_f64 = false,
+         first_generic = false, force_rescan = false, test_hooks = false;
+    int pack_min_strips = -1, strip_rows = 0, tile_rpt = 0, queue_cap = -1, mismatch_cap = -1;
+    double first_slack = -1.0;
+    char kernel[16] = {0};           // DW_KERNEL: "tiled" | "stream"
+    char text[256] = {0};            // what was set, for dw_kernel_info
+};
+static const char* test_hook(const char* name) {              // a DW_TEST_* variable, only under DW_TEST_HOOKS
+    return std::getenv("DW_TEST_HOOKS") ? std::getenv(name) : nullptr;
+}
+static Switches read_switches() {
+    Switches w;
+    auto note = [&](const char* name, const char* val) {
+        const size_t n = std::strlen(w.text);
+        snprintf(w.text + n, sizeof(w.text) - n, "%s%s%s%s", n ? " " : "", name, val ? "=" : "", val ? val : "");
+    };
+    auto flag = [&](const char* name, bool& dst) { if (std::getenv(name)) { dst = true; note(name, nullptr); } };
+    auto num = [&](const char* name, int& dst, bool test) {
+        if (const char* e = test ? test_hook(name) : std::getenv(name)) { dst = std::atoi(e); note(name, e); }
+    };
+    w.test_hooks = std::getenv("DW_TEST_HOOKS") != nullptr;
+    flag("DW_NO_SYM", w.no_sym); flag("DW_NO_PACK", w.no_pack); flag("DW_NO_FUSE", w.no_fuse); flag("DW_NO_RING", w.no_ring);
+    flag("DW_NO_EPISODE_KERNEL", w.no_episode_kernel); flag("DW_NO_EPISODE_WAVE", w.no_episode_wave);
+    flag("DW_NO_AGENT_FUSE", w.no_agent_fuse); flag("DW_NO_AGENT_PREAPPLY", w.no_agent_preapply);
+    flag("DW_FIRST_STEP_F64", w.first_f64); flag("DW_FIRST_GENERIC", w.first_generic);
+    num("DW_PACK_MIN_STRIPS", w.pack_min_strips, false); num("DW_STRIP_ROWS", w.strip_rows, false);
+    num("DW_TILE_RPT", w.tile_rpt, false);
+    num("DW_TEST_QUEUE_CAP", w.queue_cap, true); num("DW_TEST_MISMATCH_CAP", w.mismatch_cap, true);
+    if (test_hook("DW_TEST_FORCE_RESCAN")) { w.force_rescan = true; note("DW_TEST_FORCE_RESCAN", nullptr); }
+    if (const char* e = test_hook("DW_TEST_FIRST_SLACK")) { w.first_slack = std::atof(e); note("DW_TEST_FIRST_SLACK", e); }
+    if (const char* e = std::getenv("DW_KERNEL")) { snprintf(w.kernel, sizeof(w.kernel), "%s", e); note("DW_KERNEL", e); }
+    return w;
+}
+
 struct dw_handle {
     dw_params prm;
     hipStream_t stream = nullptr;
@@ -93,6 +133,7 @@ struct dw_handle {
     int* redo_tiles = nullptr;        // exact mode: tiles to recompute whole (queue overflow)
     // streaming kernel (W >= 256)
     bool use_stream = false;
+    Switches sw{};                    // experiment / test switches as they were when the handle was created
     StripGeom sgeom{};
     bool allow_fuse = false;          // wide grids: dw_step_n / dw_run_episode fuse pairs of steps
     bool fused_ring = false;          // W == 1024: the four waves of a workgroup form a ring over the torus row
@@ -164,9 +205,10 @@ static void release_unquantised(dw_handle* h) {
 
 // The two planes of an un-quantised state come and go together (dw_host_util.hpp): a failed second allocation
 // leaves NEITHER, so a retry on the same handle reports DW_ENOMEM again instead of launching on a null plane.
-// DW_TEST_FAIL_PAIR_ALLOC=<n> (tests): the second allocation of the next n pairs fails with out-of-memory.
+// DW_TEST_FAIL_PAIR_ALLOC=<n> (tests, under DW_TEST_HOOKS; process-wide countdown): the second allocation of the next n
+// pairs fails with out-of-memory.
 static int alloc_plane_pair(void** a, void** b, size_t bytes) {
-    static int fail_left = [] { const char* e = std::getenv("DW_TEST_FAIL_PAIR_ALLOC"); return e ? std::atoi(e) : 0; }();
+    static int fail_left = [] { const char* e = test_hook("DW_TEST_FAIL_PAIR_ALLOC"); return e ? std::atoi(e) : 0; }();
     int calls = 0;
     hipError_t last = hipSuccess;
     const int rc = alloc_pair_all_or_nothing(
@@ -410,7 +452,8 @@ static void derive_f32_pair(const dw_params& p, double L1, double L2, PhysF32* P
 // float32 state; stencil sums of non-integers round (2u per sum of four, 3u for the sum of eight); the density
 // carries 5u + iota; the coefficient chain is the rounded one (no exact hi part): its absolute error is
 // (8u + iota) M + u |c0| with the per-cell M the kernel evaluates.
-static FirstStepBound derive_first_bound(const dw_params& p, double L, const PhysF32& P, bool from_f64) {
+static FirstStepBound derive_first_bound(const dw_params& p, double L, const PhysF32& P, bool from_f64,
+                                         double test_slack = -1.0) {
     const double u = std::ldexp(1.0, -24), iota = from_f64 ? u : 0.0;
     const double kmax = 1000.0;
     const double To4 = std::pow(p.temp_optimal, 4), K = p.S * L / p.sigma;
@@ -454,10 +497,7 @@ static FirstStepBound derive_first_bound(const dw_params& p, double L, const Phy
     B.eA = up(safety * ((kK + 3.0 * u) + u + (kK + u)));
     B.cS = up(safety * u);                                        // the sum k + gq rounds (u |sum|); a float64 k was rounded (u k)
     B.slack = admissible ? 4e-6f : 1.0f;                          // the float32 arithmetic of eps itself; inadmissible: all float64
-    if (const char* e = std::getenv("DW_TEST_FIRST_SLACK")) {    // tests: a wider bracket flags many cells (list sweeps)
-        const float v = (float)std::atof(e);
-        if (v > B.slack) B.slack = v;
-    }
+    if (test_slack > (double)B.slack) B.slack = (float)test_slack;   // tests: a wider bracket flags many cells (list sweeps)
     return B;
 }
 
@@ -487,22 +527,22 @@ static void select_kernel(dw_handle* h) {
     h->rpt = 0;
     h->use_stream = false;
     h->allow_fuse = false;
-    h->sym_albedo = (p.albedo_dark - p.albedo_bare) == -(p.albedo_light - p.albedo_bare) && !std::getenv("DW_NO_SYM");
+    h->sym_albedo = (p.albedo_dark - p.albedo_bare) == -(p.albedo_light - p.albedo_bare) && !h->sw.no_sym;
     if (p.precision == DW_PRECISION_F64) return;
     if (p.width % 4 != 0) return;
     const int Wq = p.width / 4;
-    const char* force = std::getenv("DW_KERNEL");               // "tiled" | "stream": A/B experiments
+    const char* force = h->sw.kernel[0] ? h->sw.kernel : nullptr;   // "tiled" | "stream": A/B experiments
     // packed mode of the wave-strip kernels: narrow worlds whose width divides 256 sit side by side in one
     // 256-column wave row (256/W worlds per wave)
     // (only for ensembles with enough wave-strips to occupy the GPU: a lone strip is a serial march down
     // 64 rows, ~50 us, where the tiled kernel answers in ~9 us; DW_PACK_MIN_STRIPS overrides for tests)
     int pack_min_strips = 512;
-    if (const char* e = std::getenv("DW_PACK_MIN_STRIPS")) pack_min_strips = std::atoi(e);
+    if (h->sw.pack_min_strips >= 0) pack_min_strips = h->sw.pack_min_strips;
     // any width below 256 that is a multiple of 4, provided at least 70 % of the 64 lanes get columns
     // (W = 96: 2 worlds on 48 lanes; W = 132: one world on 33 lanes - left to the tiled kernel)
     const int pk_lpw = p.width / 4, pk_wpr = pk_lpw ? 64 / pk_lpw : 0;
     const bool pack_shape = p.width >= 8 && p.width < 256 && pk_wpr >= 1 && pk_wpr * pk_lpw * 10 >= 64 * 7 &&
-                            !std::getenv("DW_NO_PACK");
+                            !h->sw.no_pack;
     const long pack_strips = pack_shape ? (long)((p.batch + pk_wpr - 1) / pk_wpr) * ((p.height + 63) / 64) : 0;
     const bool packable = pack_shape && pack_strips >= pack_min_strips;
     if ((p.width >= 256 || packable) && !(force && std::strcmp(force, "tiled") == 0)) {
@@ -519,28 +559,22 @@ static void select_kernel(dw_handle* h) {
             const long groups = (long)(packable ? (p.batch + g.wpr - 1) / g.wpr : p.batch) * g.ncs;
             int sr = 64;
             while (sr > 8 && groups * ((p.height + sr - 1) / sr) < 2048) sr >>= 1;    // two strips per SIMD
-            if (const char* e = std::getenv("DW_STRIP_ROWS")) { const int v = std::atoi(e); if (v >= 1) sr = v; }
+            if (h->sw.strip_rows >= 1) sr = h->sw.strip_rows;
             g.SR = p.height < sr ? p.height : sr;
         }
         g.qcap = kWaveQueueCap;
         int mcap = kMismatchCap;
-        if (const char* e = std::getenv("DW_TEST_QUEUE_CAP")) {  // tests: force the overflow fallbacks
-            const int v = std::atoi(e);
-            if (v >= 0 && v < kWaveQueueCap) g.qcap = v;
-        }
-        if (const char* e = std::getenv("DW_TEST_MISMATCH_CAP")) {
-            const int v = std::atoi(e);
-            if (v >= 0 && v < kMismatchCap) mcap = v;
-        }
-        g.force_rescan = std::getenv("DW_TEST_FORCE_RESCAN") ? 1 : 0;   // tests: the strip maximum's re-scan path
-        h->allow_fuse = !std::getenv("DW_NO_FUSE");
+        if (h->sw.queue_cap >= 0 && h->sw.queue_cap < kWaveQueueCap) g.qcap = h->sw.queue_cap;   // tests: force the overflow fallbacks
+        if (h->sw.mismatch_cap >= 0 && h->sw.mismatch_cap < kMismatchCap) mcap = h->sw.mismatch_cap;
+        g.force_rescan = h->sw.force_rescan ? 1 : 0;            // tests: the strip maximum's re-scan path
+        h->allow_fuse = !h->sw.no_fuse;
         FusedGeom& f = h->fgeom;
         f.B = p.batch; f.H = p.height; f.W = p.width;
         f.SR = g.SR;
         f.lpw = g.lpw; f.wpr = g.wpr;
         // W == 1024: one WORKGROUP per row strip, its four waves side by side (edge columns through LDS) instead of
         // five overlapped 248-column strips (DW_NO_RING: experiments)
-        h->fused_ring = p.width == 1024 && !std::getenv("DW_NO_RING");
+        h->fused_ring = p.width == 1024 && !h->sw.no_ring;
         f.cols_per_strip = p.width <= 256 ? 256 : (h->fused_ring ? 1024 : 248);
         f.ncs = packable ? 1 : (p.width + f.cols_per_strip - 1) / f.cols_per_strip;
         f.qcap = g.qcap;
@@ -551,10 +585,7 @@ static void select_kernel(dw_handle* h) {
     }
     if (Wq >= 64) {
         h->tcq = 64; h->rpt = 4;
-        if (const char* e = std::getenv("DW_TILE_RPT")) {      // tuning experiments only
-            const int r = std::atoi(e);
-            if (r == 2 || r == 4 || r == 8) h->rpt = r;
-        }
+        if (h->sw.tile_rpt == 2 || h->sw.tile_rpt == 4 || h->sw.tile_rpt == 8) h->rpt = h->sw.tile_rpt;   // tuning experiments only
     }
     else if (Wq >= 32) { h->tcq = 32; h->rpt = 4; }
     else if (Wq >= 16) { h->tcq = 16; h->rpt = 2; }
@@ -567,10 +598,7 @@ static void select_kernel(dw_handle* h) {
     g.ntiles = p.batch * g.tiles_r * g.tiles_c;
     g.chunk = (g.ntiles + 7) / 8;
     g.qcap = kMaxFix;
-    if (const char* e = std::getenv("DW_TEST_QUEUE_CAP")) {      // tests: force the overflow fallbacks
-        const int v = std::atoi(e);
-        if (v >= 0 && v < kMaxFix) g.qcap = v;
-    }
+    if (h->sw.queue_cap >= 0 && h->sw.queue_cap < kMaxFix) g.qcap = h->sw.queue_cap;   // tests: force the overflow fallbacks
     h->tile_lds = (size_t)2 * (TR + 2) * (h->tcq + 2) * 4 * sizeof(float);
 }
 
@@ -643,31 +671,38 @@ static int launch_forward(dw_handle* h, double L) {
                        p.height, p.width, P, P64, stats, fixups, zero_me, zero_n, gcpt)
         // exact mode: float32 with the tie bound for non-integer inputs, float64 only for the flagged cells
         // (DW_FIRST_STEP_F64=1: every cell in float64, as in round 2 - experiments)
-        static const bool first_f64 = std::getenv("DW_FIRST_STEP_F64") != nullptr;
+        const bool first_f64 = h->sw.first_f64;
         const bool f32arith = prec == DW_PRECISION_FAST;
         const bool bounded = prec == DW_PRECISION_EXACT && !first_f64;
 #define DW_GEN3(T, IL, ID, FB)                                                                                    \
     hipLaunchKernelGGL((step_generic<T, 3>), ggrid, dim3(256), 0, h->stream, IL, ID, h->L16[out], h->D16[out],    \
                        p.height, p.width, P, P64, stats, fixups, zero_me, zero_n, gcpt, FB)
-        // widths that are multiples of 256: the wave-strip form of the same arithmetic (dw_step_first.hpp; ~4x fewer
-        // vector instructions per cell).  DW_FIRST_GENERIC=1: the one-thread-per-cell kernel (experiments, tests)
-        const bool first_stream = p.width % 256 == 0 && (f32arith || bounded) && !std::getenv("DW_FIRST_GENERIC");
+        // every shape the steady-state wave-strip kernels take (select_kernel: W >= 256 a multiple of 4, or the packed
+        // mode of narrower worlds; and any multiple of 256): the wave-strip form of the same arithmetic (dw_step_first.hpp;
+        // ~4x fewer vector instructions per cell).  DW_FIRST_GENERIC=1: the one-thread-per-cell kernel (experiments, tests)
+        const bool first_stream = (p.width % 256 == 0 || h->use_stream) && (f32arith || bounded) && !h->sw.first_generic;
         if (first_stream) {
+            const bool packed = h->use_stream && p.width < 256;
             FirstGeom fg;
             fg.B = p.batch; fg.H = p.height; fg.W = p.width;
-            fg.ncs = p.width / 256;
+            fg.lpw = packed ? h->sgeom.lpw : 64;
+            fg.wpr = packed ? h->sgeom.wpr : 1;
+            fg.ncs = packed ? 1 : (p.width + 255) / 256;
+            const long groups = packed ? (p.batch + fg.wpr - 1) / fg.wpr : p.batch;
             int sr = 64;                                         // shorter strips until every SIMD has four
-            while (sr > 8 && (long)p.batch * fg.ncs * ((p.height + sr - 1) / sr) < 4096) sr >>= 1;
+            while (sr > 8 && groups * fg.ncs * ((p.height + sr - 1) / sr) < 4096) sr >>= 1;
             fg.SR = p.height < sr ? p.height : sr;
             fg.nrs = (p.height + fg.SR - 1) / fg.SR;
-            fg.nstrips = p.batch * fg.nrs * fg.ncs;
+            fg.nstrips = (int)(groups * fg.nrs * fg.ncs);
+            const int fhalo = packed ? 3 : (p.width == 256 ? 0 : (p.width % 256 == 0 ? 1 : 2));
             const dim3 fgrid((unsigned)((fg.nstrips + 3) / 4));
-            const FirstStepBound fb = bounded ? derive_first_bound(p, L, P, h->unq_kind == UNQ_F64) : FirstStepBound{};
+            const FirstStepBound fb = bounded ? derive_first_bound(p, L, P, h->unq_kind == UNQ_F64, h->sw.first_slack) : FirstStepBound{};
 #define DW_FIRST(T, PR, HL, IL, ID)                                                                               \
     hipLaunchKernelGGL((step_first_stream<T, PR, HL>), fgrid, dim3(256), 0, h->stream, IL, ID, h->L16[out],       \
                        h->D16[out], fg, P, P64, stats, fixups, zero_me, zero_n, fb)
 #define DW_FIRST_HL(T, PR, IL, ID)                                                                                \
-    do { if (fg.ncs == 1) DW_FIRST(T, PR, 0, IL, ID); else DW_FIRST(T, PR, 1, IL, ID); } while (0)
+    do { if (fhalo == 0) DW_FIRST(T, PR, 0, IL, ID); else if (fhalo == 1) DW_FIRST(T, PR, 1, IL, ID);           \
+         else if (fhalo == 2) DW_FIRST(T, PR, 2, IL, ID); else DW_FIRST(T, PR, 3, IL, ID); } while (0)
             if (h->unq_kind == UNQ_F64) {
                 if (f32arith) DW_FIRST_HL(double, 1, h->L64, h->D64);
                 else DW_FIRST_HL(double, 3, h->L64, h->D64);
@@ -679,11 +714,11 @@ static int launch_forward(dw_handle* h, double L) {
 #undef DW_FIRST
         } else if (h->unq_kind == UNQ_F64) {
             if (f32arith) DW_GEN(double, 1, h->L64, h->D64);
-            else if (bounded) DW_GEN3(double, h->L64, h->D64, derive_first_bound(p, L, P, true));
+            else if (bounded) DW_GEN3(double, h->L64, h->D64, derive_first_bound(p, L, P, true, h->sw.first_slack));
             else DW_GEN(double, 2, h->L64, h->D64);
         } else {
             if (f32arith) DW_GEN(float, 1, h->U32L, h->U32D);
-            else if (bounded) DW_GEN3(float, h->U32L, h->U32D, derive_first_bound(p, L, P, false));
+            else if (bounded) DW_GEN3(float, h->U32L, h->U32D, derive_first_bound(p, L, P, false, h->sw.first_slack));
             else DW_GEN(float, 2, h->U32L, h->U32D);
         }
 #undef DW_GEN3
@@ -942,6 +977,7 @@ int dw_create(const dw_params* p, dw_handle** out) {
         TRY(hipMalloc(&h->stats2[i], h->stats_bytes));
         TRY(hipMemsetAsync(h->stats2[i], 0, h->stats_bytes, h->stream));
     }
+    h->sw = read_switches();                                    // the environment is read here and nowhere else
     select_kernel(h);
     if (int qrc = ensure_fixq(h)) return cleanup(qrc);
     TRY(hipMemsetAsync(h->action, 0, sizeof(int) * bn, h->stream));
@@ -1805,11 +1841,11 @@ int dw_run_episode_mlp(dw_handle* h, int32_t nsteps, const double* L_schedule, c
     const int Cc = p.height * p.width;
     const int wpb = Cc <= 256 ? 4 : (Cc <= 1024 ? 2 : 1);
     // H*W <= 256 with at most four agents (the ES trainers' own 16x16 x 4): one wave per world (dw_episode_wave.hpp)
-    const bool wave_kernel = Cc <= kEwMaxCells && 16 * N <= 64 && !std::getenv("DW_NO_EPISODE_WAVE");
+    const bool wave_kernel = Cc <= kEwMaxCells && 16 * N <= 64 && !h->sw.no_episode_wave;
     const size_t lds = wave_kernel ? episode_wave_shared_bytes() + episode_mlp_wave_world_bytes(Cc, N) * 4
                                    : episode_mlp_world_bytes(Cc, N) * wpb;
     const bool small = Cc <= 4096 && lds <= 160 * 1024 && p.precision != DW_PRECISION_F64 &&
-                       !std::getenv("DW_NO_EPISODE_KERNEL");
+                       !h->sw.no_episode_kernel;
     std::vector<PhysF32> p32;
     SyncOnExit guard2(h->stream);                             // p32 (filled below) must outlive its upload
     size_t t = 0;
@@ -1922,7 +1958,7 @@ int dw_run_episode(dw_handle* h, int32_t nsteps, const double* L_schedule, int p
 static bool episode_kernel_applies(const dw_handle* h) {
     const dw_params& p = h->prm;
     return p.height * p.width <= 4096 && p.precision != DW_PRECISION_F64 && p.collision_mode == 0 &&
-           cur_quantised(h) && !std::getenv("DW_NO_EPISODE_KERNEL");
+           cur_quantised(h) && !h->sw.no_episode_kernel;
 }
 
 // dw_run_episode for worlds that do not fit LDS: the same K steps as K x (policy, dw_step) issued
@@ -1947,7 +1983,7 @@ static int run_episode_stepwise(dw_handle* h, int32_t nsteps, const double* L_sc
     // call stays an ordinary step, so the handle ends exactly as after K calls of dw_step.
     const bool may_pair = h->allow_fuse && h->use_stream && bn && N <= kLookaheadMaxAgents &&
                           policy_mode != kPolicySkipAgents && p.precision != DW_PRECISION_F64 &&
-                          !std::getenv("DW_NO_AGENT_FUSE");
+                          !h->sw.no_agent_fuse;
     // With per-step world flags the fused launch also reduces what the flags of both steps need (STATS
     // variants: exact step-1 maximum, count of certain step-2 values above the threshold).
     unsigned int* pstats = world_alive ? reinterpret_cast<unsigned int*>(h->ep_buf + o_ps) : nullptr;
@@ -1960,7 +1996,7 @@ static int run_episode_stepwise(dw_handle* h, int32_t nsteps, const double* L_sc
     auto greedy = [&](int argmin, int codes) { return launch_policy_greedy(h, argmin, nullptr, codes); };
     // policy + update_agents of the step after a pair run inside that pair's patch kernel (phase E) while the chunk
     // continues: two launches per pair instead of four (DW_NO_AGENT_PREAPPLY: experiments)
-    static const bool no_preapply = std::getenv("DW_NO_AGENT_PREAPPLY") != nullptr;
+    const bool no_preapply = h->sw.no_agent_preapply;
     bool pre_applied = false;
     for (size_t t = 0; t < K; ++t) {
         const bool pair = may_pair && cur_quantised(h) && K - t >= 3;
@@ -2047,11 +2083,11 @@ static int run_episode_impl(dw_handle* h, int32_t nsteps, const double* L_schedu
     NEED(policy_mode != DW_POLICY_TABLE || table, DW_EINVAL, "DW_POLICY_TABLE needs a table");
     if (use_table && !table)
         for (int t = 0; t < nsteps; ++t) NEED(!use_table[t], DW_EINVAL, "use_table set but no table given");
-    if (C > 4096 || std::getenv("DW_NO_EPISODE_KERNEL"))
+    if (C > 4096 || h->sw.no_episode_kernel)
         return run_episode_stepwise(h, nsteps, L_schedule, policy_mode, use_table, table, threshold_k, world_alive,
                                     agent_ok);
     // H*W <= 256 (the README sweep's 8x8, the ES trainers' 16x16): one wave per world (dw_episode_wave.hpp)
-    const bool wave_kernel = C <= kEwMaxCells && N <= 64 && !std::getenv("DW_NO_EPISODE_WAVE");
+    const bool wave_kernel = C <= kEwMaxCells && N <= 64 && !h->sw.no_episode_wave;
     const int wpb = C <= 256 ? 4 : (C <= 1024 ? 2 : 1);
     const size_t world_bytes = wave_kernel ? episode_wave_world_bytes(C, N) : episode_world_bytes(C, N);
     const size_t lds = world_bytes * wpb + (wave_kernel ? episode_wave_shared_bytes() : 0);
@@ -2302,6 +2338,10 @@ int dw_kernel_info(dw_handle* h, char* buf, size_t buflen) {
     } else {
         snprintf(buf, buflen, "step_generic<%s> one thread per cell, grid=(%d,%d) x 256 threads", prec,
                  (p.height * p.width + 255) / 256, p.batch);
+    }
+    if (h->sw.text[0]) {                                        // the switches this handle was created under
+        const size_t n = std::strlen(buf);
+        snprintf(buf + n, buflen - n, "; switches[%s]", h->sw.text);
     }
     return DW_OK;
 }

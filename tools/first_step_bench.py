@@ -23,8 +23,14 @@ for B, G in zip(args[0::2], args[1::2]):
             eng.step(0.75)
             times.append(eng.timer_stop())
         fix = eng.last_fixup_count()
+        later = []                                               # an ordinary single step from the quantised state, for scale
+        for rep in range(3):
+            eng.timer_start()
+            eng.step(0.76)
+            later.append(eng.timer_stop())
         eng.close()
         for k in env:                                            # (read by the library at every launch)
             os.environ.pop(k)
         print(f"{B} x {G}^2 {prec:5s} {'one thread per cell' if env else 'default':19s} first step: {min(times):9.3f} ms (min of 3), "
-              f"float64 cells {fix} = {100.0 * fix / (B * G * G):.4f} %", flush=True)
+              f"float64 cells {fix} = {100.0 * fix / (B * G * G):.4f} %; an ordinary single step: {min(later):.3f} ms "
+              f"(ratio {min(times) / min(later):.2f})", flush=True)

@@ -7,6 +7,8 @@ flags, grid, agents, L, step_count), with the legacy NumPy RNG stream kept in lo
 
 usage: fuzz_dropin.py [cases=40] [seed=1]"""
 import os
+
+os.environ.setdefault("DW_TEST_HOOKS", "1")     # the DW_TEST_* queue caps below are honoured only under it
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

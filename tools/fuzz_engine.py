@@ -9,6 +9,8 @@ with the model.
 usage: fuzz_engine.py [cases=30] [seed=1]"""
 import copy
 import os
+
+os.environ.setdefault("DW_TEST_HOOKS", "1")     # the DW_TEST_* queue caps below are honoured only under it
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -8,6 +8,8 @@ The audit of the tie bound (dw_audit_tie_bound) is evaluated along the way.
 
 usage: fuzz_exact.py [cases=100] [seed=1] [only=<case index>]"""
 import os
+
+os.environ.setdefault("DW_TEST_HOOKS", "1")     # the DW_TEST_* queue caps below are honoured only under it
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

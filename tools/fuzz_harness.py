@@ -6,6 +6,8 @@ state the environment is left in and the legacy RNG stream must all be identical
 
 usage: fuzz_harness.py [cases=30] [seed=1]"""
 import os
+
+os.environ.setdefault("DW_TEST_HOOKS", "1")     # the DW_TEST_* queue caps below are honoured only under it
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

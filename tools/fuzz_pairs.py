@@ -5,6 +5,8 @@ against one launch per step (DW_NO_AGENT_FUSE=1), everything compared bit for bi
 
 usage: fuzz_pairs.py [cases=60] [seed=1]"""
 import os
+
+os.environ.setdefault("DW_TEST_HOOKS", "1")     # the DW_TEST_* queue caps below are honoured only under it
 import subprocess
 import sys
 
