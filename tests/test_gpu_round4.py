@@ -99,3 +99,47 @@ def test_ft_convolve_on_device_matches_reference_fixture_g6(golden):
         ft_convolve(x, np.ones((1, 1, 10, 24)))                               # the reference's un-padded branch
     with pytest.raises(ValueError):
         ft_convolve(x[0], k)
+
+
+_FAMILIES = {                                       # kernel family -> (B, H, W, extra environment)
+    "rotate": (3, 100, 256, {}),                    # W == 256: the wrap is a rotation inside the wave
+    "dpp_old": (2, 70, 512, {}),                    # W a multiple of 256
+    "ring": (2, 40, 1024, {}),                      # W == 1024: step pairs by the four-wave ring
+    "general": (2, 66, 516, {}),                    # any other multiple of 4 above 256 (narrow last strip, overlapped pairs)
+    "packed": (9, 50, 64, {"DW_PACK_MIN_STRIPS": "1"}),
+    "packed_odd_group": (5, 40, 96, {"DW_PACK_MIN_STRIPS": "1"}),      # 24 lanes per world: gathering lane groups
+    "tiled": (3, 64, 128, {"DW_PACK_MIN_STRIPS": "100000"}),
+}
+
+
+@pytest.mark.parametrize("family", sorted(_FAMILIES))
+@pytest.mark.parametrize("qcap,mcap", [(1, 0), (1, 2), (4, 1), (16, 0), (16, 2), (40, 1)])
+def test_shrunk_repair_queues_in_every_kernel_family(amd, monkeypatch, family, qcap, mcap):
+    """the sweep / overflow / reduction interplay of the exact mode is its fragile spot (a round-3
+    regression lived there) - six shrunk-queue cases PER KERNEL FAMILY stay in the GPU suite: from the un-quantised
+    Philox state (first-step kernel), a first single step, then 9 more steps through dw_step_n (four step pairs + a
+    closing single step on the wave-strip families), queues cut to 1 .. 40 entries and mismatch lists to 0 .. 2: planes
+    and all three reductions equal the float64 C oracle's."""
+    B, H, W, env = _FAMILIES[family]
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    monkeypatch.setenv("DW_NO_EPISODE_KERNEL", "1")
+    monkeypatch.setenv("DW_TEST_QUEUE_CAP", str(qcap))
+    monkeypatch.setenv("DW_TEST_MISMATCH_CAP", str(mcap))
+    eng = _engine(amd, B, H, W, 0, "exact")
+    assert f"DW_TEST_QUEUE_CAP={qcap}" in eng.kernel_info()      # the handle reports the switches it was created under
+    eng.init_random(31 + qcap)
+    light, dark = eng.download_planes()
+    L = 1.05
+    for chunk in (1, 9):
+        Lg = eng.step_n(chunk, L, 0.004, 0.75, 1.5)
+        Lo = c_oracle.step_n(light, dark, L, 0.004, chunk)
+        assert Lg == Lo
+        L = Lg
+        gl, gd = eng.download_planes()
+        assert np.array_equal(_k(gl), _k(light)) and np.array_equal(_k(gd), _k(dark)), (family, qcap, mcap, chunk)
+        s = eng.reduce()
+        assert np.array_equal(s["max_k"], np.maximum(_k(light).max(axis=(1, 2)), _k(dark).max(axis=(1, 2))))
+        assert np.array_equal(s["sum_light_k"], _k(light).sum(axis=(1, 2)))
+        assert np.array_equal(s["sum_dark_k"], _k(dark).sum(axis=(1, 2)))
+    eng.close()

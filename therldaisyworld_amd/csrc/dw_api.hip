@@ -1857,7 +1857,7 @@ int dw_run_episode_mlp(dw_handle* h, int32_t nsteps, const double* L_schedule, c
             HIPCHK(hipMemcpyAsync(h->ep_buf + o_p32, p32.data(), sizeof(PhysF32) * Kr, hipMemcpyHostToDevice, h->stream));
             HIPCHK(hipMemcpyAsync(h->ep_buf + o_ls, L_schedule + t, sizeof(double) * Kr, hipMemcpyHostToDevice, h->stream));
             StatsDev* stats = h->stats2[h->sp];
-            HIPCHK(hipMemsetAsync(stats, 0, sizeof(StatsDev) * (B + 1), h->stream));
+            if (!wave_kernel) HIPCHK(hipMemsetAsync(stats, 0, sizeof(StatsDev) * (B + 1), h->stream));   // (the wave kernel assigns every record)
             EpisodeMlpIO io;
             const int cur = h->cur, prev = 1 - h->cur;
             io.L = h->L16[cur]; io.D = h->D16[cur]; io.prevL = h->L16[prev]; io.prevD = h->D16[prev];
@@ -2135,8 +2135,9 @@ static int run_episode_impl(dw_handle* h, int32_t nsteps, const double* L_schedu
         if (table && bn) HIPCHK(hipMemcpyAsync(h->ep_buf + o_tab, table, K * bn, hipMemcpyHostToDevice, h->stream));
     }
     StatsDev* stats = h->stats2[h->sp];
-    // (every world's record is assigned by its kernel; only the float64 counter behind them is accumulated)
-    HIPCHK(hipMemsetAsync(&stats[B], 0, sizeof(StatsDev), h->stream));
+    // episode_wave ASSIGNS every world's whole record (its float64 count in `reserved`) and the counter record behind them:
+    // nothing to clear; episode_small accumulates: cleared as before
+    if (!wave_kernel) HIPCHK(hipMemsetAsync(stats, 0, sizeof(StatsDev) * (B + 1), h->stream));
     EpisodeIO io;
     const int cur = h->cur, prev = 1 - h->cur;
     io.L = h->L16[cur]; io.D = h->D16[cur]; io.prevL = h->L16[prev]; io.prevD = h->D16[prev];
@@ -2372,9 +2373,13 @@ int dw_audit_tie_bound(dw_handle* h, double L, double out[4]) {
 int dw_last_fixup_count(dw_handle* h, uint64_t* count) {
     NEED(h && count, DW_EINVAL, "null argument");
     HIPCHK(hipSetDevice(h->prm.device));
-    unsigned long long v = 0;
-    HIPCHK(hipMemcpyAsync(&v, &h->stats2[h->sp][h->prm.batch].sum_l, sizeof(v), hipMemcpyDeviceToHost, h->stream));
+    // the counter behind the per-world records + the per-world counts of the one-wave-per-world episode kernels (`reserved`:
+    // zero after every other kernel - the step kernels clear the whole buffer for the step after them)
+    std::vector<StatsDev> st((size_t)h->prm.batch + 1);
+    HIPCHK(hipMemcpyAsync(st.data(), h->stats2[h->sp], sizeof(StatsDev) * st.size(), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    unsigned long long v = st[h->prm.batch].sum_l;
+    for (int b = 0; b < h->prm.batch; ++b) v += st[b].reserved;
     *count = v;
     return DW_OK;
 }

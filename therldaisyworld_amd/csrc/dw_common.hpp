@@ -10,7 +10,7 @@ namespace dw {
 
 struct StatsDev {             // mirrors dw_world_stats
     unsigned int max_k;
-    unsigned int reserved;
+    unsigned int reserved;    // the one-wave-per-world episode kernels: float64 re-evaluations of the world's last step
     unsigned long long sum_l;
     unsigned long long sum_d;
 };

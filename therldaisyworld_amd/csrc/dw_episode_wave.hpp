@@ -333,11 +333,12 @@ __global__ __launch_bounds__(256) void episode_wave(EpisodeWaveArgs A) {
         sl = wave_sum(sl);                                       // integers < 2^24: exact in any order
         sd = wave_sum(sd);
         const unsigned int nf = (unsigned int)wave_sum((float)last_fix);
-        if (lane == 0) {
+        if (lane == 0) {                                        // the world's whole record is ASSIGNED: no memset before the launch
+            if (b == 0) io.stats[B] = StatsDev{0u, 0u, 0ull, 0ull};   // ... and the counter record behind the worlds'
             io.stats[b].max_k = (unsigned int)m;
+            io.stats[b].reserved = EXACT ? nf : 0u;              // float64 re-evaluations of the last step (dw_last_fixup_count sums them)
             io.stats[b].sum_l = (unsigned long long)sl;
             io.stats[b].sum_d = (unsigned long long)sd;
-            if (EXACT && nf) atomicAdd(io.fixups, (unsigned long long)nf);
         }
     }
 }
@@ -569,10 +570,11 @@ __global__ __launch_bounds__(256) void episode_mlp_wave(EpisodeMlpWaveArgs A) {
         sd = wave_sum(sd);
         const unsigned int nf = (unsigned int)wave_sum((float)last_fix);
         if (lane == 0) {
+            if (b == 0) io.stats[B] = StatsDev{0u, 0u, 0ull, 0ull};
             io.stats[b].max_k = (unsigned int)m;
+            io.stats[b].reserved = EXACT ? nf : 0u;
             io.stats[b].sum_l = (unsigned long long)sl;
             io.stats[b].sum_d = (unsigned long long)sd;
-            if (EXACT && nf) atomicAdd(io.fixups, (unsigned long long)nf);
         }
     }
 }
