@@ -123,7 +123,7 @@ typedef struct dw_params {
  * per-mille units, hence exact and order-independent. */
 typedef struct dw_world_stats {
     uint32_t max_k;        /* max over light and dark cells of 1000*cover */
-    uint32_t reserved;
+    uint32_t reserved;     /* library-internal (a diagnostic count behind dw_last_fixup_count); do not interpret */
     uint64_t sum_light_k;  /* sum over cells of 1000*light */
     uint64_t sum_dark_k;   /* sum over cells of 1000*dark  */
 } dw_world_stats;
@@ -353,7 +353,8 @@ int dw_lifespan_download(dw_handle* h, int32_t* done_at /* [B] */, int32_t* agen
 
 /* Device-resident episode loop: K consecutive environment steps — policy,
  * update_agents (ref :181-244), forward (ref :434-461), reductions — without a host round trip per
- * step.  Small worlds (H*W <= 4096) run in ONE launch with the worlds held in LDS; larger worlds run the
+ * step.  Small worlds (H*W <= 4096) run in ONE launch with the worlds held in LDS (H*W <= 256 - the reference's own 8x8
+ * and 16x16 worlds - one wave per world with no workgroup barrier in the step: csrc/dw_episode_wave.hpp); larger worlds run the
  * same K steps as back-to-back launches on the handle's stream (policy / table slice, update_agents, the
  * streaming step kernel, flags from its reductions) with one synchronisation at the end.  It is the body of the
  * reference's lifespan harness (notebooks/greedy_longevity_abatement.ipynb cell 2:28-57) and of

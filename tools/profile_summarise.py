@@ -53,7 +53,7 @@ for prec in ("exact", "fast"):
     json.dump(line, open(os.path.join(root, "profiles", f"{tag}_bench_{wl}_{prec}.json"), "w"))
     fetch = counter_avg(find(f"pmc_{prec}_FETCH_SIZE/**/*counter_collection.csv"), "FETCH_SIZE")
     write = counter_avg(find(f"pmc_{prec}_WRITE_SIZE/**/*counter_collection.csv"), "WRITE_SIZE")
-    out = {"workload": wl, "precision": prec, "round": 3, "tag": tag, "plane_elem_bytes": 2, "shape": desc,
+    out = {"workload": wl, "precision": prec, "round": int(tag[1:3]) if tag[1:3].isdigit() else 0, "tag": tag, "plane_elem_bytes": 2, "shape": desc,
            "worlds_per_gpu": cfg["worlds_per_gpu"], "grid": cfg["grid"],
            "library_build_id": cfg.get("library_build_id"),         # bench.py flags the derived fields stale when
                                                                       # the live library was built from other sources
@@ -94,7 +94,7 @@ for prec in ("exact", "fast"):
           f"avg {main.get('rocprofv3_kernel_avg_ns', 0) / 1e6:.4f} ms")
     # ---- SQ counters of the fused kernel
     if valu_out is None:
-        valu_out = {"round": 3, "tag": tag, "workload": desc, "plane_elem_bytes": 2,
+        valu_out = {"round": int(tag[1:3]) if tag[1:3].isdigit() else 0, "tag": tag, "workload": desc, "plane_elem_bytes": 2,
                     "library_build_id": cfg.get("library_build_id"), "worlds_per_gpu": cfg["worlds_per_gpu"],
                     "grid": cfg["grid"],
                     "note": "rocprofv3 --kernel-trace --pmc <two counters per pass>; per-launch averages over the dispatches "
