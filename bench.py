@@ -326,11 +326,11 @@ def main():
                     table[:, :, 8:12] = rng.randint(9, size=(k, B, 4))
                     coin = rng.rand(k) > 0.5
                     table[:, :, 12:16] = np.where(coin[:, None, None], -1, rng.randint(9, size=(k, B, 4)))
-                    eng.run_episode(Ls, _ffi.POLICY_TABLE, None, table, world_flags=False)
+                    eng.run_episode(Ls, _ffi.POLICY_TABLE, None, table, world_flags=False, reuse_buffers=True)
                 elif workload in ("c4", "c4_dim8"):
-                    eng.run_episode(Ls, _ffi.POLICY_ARGMAX)         # with the per-step world flags of the sweep
+                    eng.run_episode(Ls, _ffi.POLICY_ARGMAX, reuse_buffers=True)     # with the per-step world flags of the sweep
                 else:
-                    eng.run_episode(Ls, _ffi.POLICY_ARGMAX, world_flags=False)
+                    eng.run_episode(Ls, _ffi.POLICY_ARGMAX, world_flags=False, reuse_buffers=True)
                 nsteps -= k
             return L
 

@@ -288,7 +288,8 @@ class Engine:
     def snapshot_restore(self):
         self._check(self._lib.dw_snapshot_restore(self._h))
 
-    def run_episode(self, L_schedule, policy_mode, use_table=None, table=None, threshold_k=5, world_flags=True):
+    def run_episode(self, L_schedule, policy_mode, use_table=None, table=None, threshold_k=5, world_flags=True,
+                    reuse_buffers=False):
         """K device-resident steps (one launch for H*W <= 4096, back-to-back launches otherwise).
         Returns (world_alive (K,B) bool, agent_ok (K,B,N) bool).  `table` entries: 0..8 an action, -1 / -2 the
         greedy / anti-greedy choice of that agent at that step.  world_flags=False: the per-step world
@@ -303,8 +304,20 @@ class Engine:
         if tb is not None and tb.shape != (K, self.B, self.N):
             raise ValueError(f"table must have shape {(K, self.B, self.N)}")
         # (the library writes every flag as 0 / 1: the uint8 arrays are returned as bool VIEWS, no second pass)
-        alive = np.empty((K, self.B), dtype=np.uint8) if world_flags else None
-        ok = np.empty((K, self.B, self.N), dtype=np.uint8)
+        # reuse_buffers=True: the flag arrays are this engine's own and are OVERWRITTEN by the next such call (a fresh
+        # 256 KB array per chunk is a fresh mmap: ~60 page faults while the library copies into it) - for loops that
+        # consume a chunk's flags before they run the next chunk
+        if reuse_buffers:
+            cache = self.__dict__.setdefault("_flag_buffers", {})
+            key = (K, bool(world_flags))
+            if key not in cache:
+                cache.clear()
+                cache[key] = (np.empty((K, self.B), dtype=np.uint8) if world_flags else None,
+                              np.empty((K, self.B, self.N), dtype=np.uint8))
+            alive, ok = cache[key]
+        else:
+            alive = np.empty((K, self.B), dtype=np.uint8) if world_flags else None
+            ok = np.empty((K, self.B, self.N), dtype=np.uint8)
         self._check(self._lib.dw_run_episode(
             self._h, K, _ffi.ptr_d(Ls), int(policy_mode), _ffi.ptr_u8(ut),
             None if tb is None else tb.ctypes.data_as(C.POINTER(C.c_int8)), int(threshold_k), _ffi.ptr_u8(alive),

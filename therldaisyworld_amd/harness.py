@@ -145,7 +145,8 @@ def simulate_lifespan(env, agent, chunk=32, use_device_loop=True, obs=None, fina
             def on_device():
                 if final_state:
                     eng.snapshot_save()
-                return eng.run_episode(Ls, mode, use_table, table, LIFESPAN_THRESHOLD_K)
+                # (the chunk's flags are summed below before the next chunk runs: the engine's own flag buffers are re-used)
+                return eng.run_episode(Ls, mode, use_table, table, LIFESPAN_THRESHOLD_K, reuse_buffers=True)
 
             if pool is not None:
                 pending = pool.submit(on_device)
