@@ -114,12 +114,12 @@ __global__ void observe(const PrevT* __restrict__ pL, const PrevT* __restrict__ 
     const CellF64 o = cell_f64(P, l9, d9);
     double v[7];
     if (POST) {
-        v[0] = dw_round3_k(P.p - o.nl - o.nd) / 1000.0;
+        v[0] = dw_div1000(dw_round3_k(P.p - o.nl - o.nd));
         v[1] = to_natural(cL[woff + (size_t)r * W + c]);
         v[2] = to_natural(cD[woff + (size_t)r * W + c]);
-        v[3] = dw_round3_k(o.T) / 1000.0;
-        v[4] = dw_round3_k(o.Tl) / 1000.0;
-        v[5] = dw_round3_k(o.Td) / 1000.0;
+        v[3] = dw_div1000(dw_round3_k(o.T));
+        v[4] = dw_div1000(dw_round3_k(o.Tl));
+        v[5] = dw_div1000(dw_round3_k(o.Td));
     } else {
         v[0] = P.p - l9[4] - d9[4]; v[1] = l9[4]; v[2] = d9[4];
         v[3] = o.T; v[4] = o.Tl; v[5] = o.Td;

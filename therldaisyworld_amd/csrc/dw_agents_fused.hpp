@@ -31,7 +31,7 @@ constexpr int kLookaheadMaxAgents = 64;      // agents per world handled by one 
 template <typename TI>
 __device__ inline unsigned int fast1_word(const TI* __restrict__ pL, const TI* __restrict__ pD, int H, int W, int r,
                                           int c, const PhysF32& P) {
-    const int rr = ((r % H) + H) % H, cc = ((c % W) + W) % W;
+    const int rr = wrap_near2(r, H), cc = wrap_near2(c, W);    // (callers pass in-range coordinates +- 2: no division)
     const int ru = rr == 0 ? H - 1 : rr - 1, rd = rr == H - 1 ? 0 : rr + 1;
     const int cl = cc == 0 ? W - 1 : cc - 1, cr = cc == W - 1 ? 0 : cc + 1;
     auto at = [&](const TI* p, int row, int col) -> float { return (float)p[(size_t)row * W + col]; };
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(64) void agents_lookahead_patch(LookaheadArgs A) {
                 const unsigned int w = s_s1[lane][i + 1];
                 double val = 0.0;
                 if ((A.mask >> cand[i]) & 1)
-                    val = (double)(float)(w & 0xffffu) / 1000.0 + (double)(float)(w >> 16) / 1000.0;
+                    val = dw_permille_to_natural((double)(float)(w & 0xffffu)) + dw_permille_to_natural((double)(float)(w >> 16));
                 if (i == 0 || (argmin ? val < bestv : val > bestv)) { best = i; bestv = val; }
             }
             a = 4 + best;
@@ -162,8 +162,8 @@ __global__ __launch_bounds__(64) void agents_lookahead_patch(LookaheadArgs A) {
                     if (m == 0) { c -= 1; which = 1; } else if (m == 1) { r -= 1; which = 2; }
                     else if (m == 2) { r += 1; which = 3; } else { c += 1; which = 4; }
                 }
-                r = ((r % H) + H) % H;                                                      // ref :208
-                c = ((c % W) + W) % W;
+                r = wrap_near(r, H);                                                        // ref :208 (in range +- 1)
+                c = wrap_near(c, W);
                 s_ar[n] = r;
                 s_ac[n] = c;
                 if (a > 4) {                                                                // ref :210-216
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(64) void agents_lookahead_patch(LookaheadArgs A) {
                     for (int g = 0; g < ng; ++g) eaten = eaten || (s_gr[g] == r && s_gc[g] == c);
                     if (!eaten) {
                         const unsigned int w = s_s1[n][which];
-                        s += (double)(float)(w & 0xffffu) / 1000.0 + (double)(float)(w >> 16) / 1000.0;
+                        s += dw_permille_to_natural((double)(float)(w & 0xffffu)) + dw_permille_to_natural((double)(float)(w >> 16));
                         s_gr[ng] = r; s_gc[ng] = c; ++ng;
                     }
                     s_st[n] = s;
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(64) void agents_lookahead_patch(LookaheadArgs A) {
     const int ng = s_ng;
     for (int p = lane; p < ng * 25; p += 64) {
         const int g = p / 25, t = p - g * 25;
-        const int yr = ((s_gr[g] + t / 5 - 2) % H + H) % H, yc = ((s_gc[g] + t % 5 - 2) % W + W) % W;
+        const int yr = wrap_near2(s_gr[g] + t / 5 - 2, H), yc = wrap_near2(s_gc[g] + t % 5 - 2, W);
         bool grazed = false;
         for (int k = 0; k < ng; ++k) grazed = grazed || (s_gr[k] == yr && s_gc[k] == yc);
         s_w[g][t] = grazed ? 0u : step1(yr, yc);
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(64) void agents_lookahead_patch(LookaheadArgs A) {
     for (int p = lane; p < ng * 9; p += 64) {
         const int g = p / 9, t = p - g * 9;
         const int tr = t / 3, tc = t - tr * 3;                   // the S2 cell is block cell (tr + 1, tc + 1) of the 5x5
-        const int xr = ((s_gr[g] + tr - 1) % H + H) % H, xc = ((s_gc[g] + tc - 1) % W + W) % W;
+        const int xr = wrap_near(s_gr[g] + tr - 1, H), xc = wrap_near(s_gc[g] + tc - 1, W);
         unsigned int w2[9];
 #pragma unroll
         for (int a = 0; a < 3; ++a)
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(64) void agents_lookahead_patch(LookaheadArgs A) {
             const int dr[5] = {0, 0, -1, 1, 0}, dc[5] = {0, -1, 0, 0, 1};
             for (int t = lane; t < N * 5; t += 64) {
                 const int n = t / 5, i = t - n * 5;
-                const int r = ((s_ar[n] + dr[i]) % H + H) % H, c = ((s_ac[n] + dc[i]) % W + W) % W;
+                const int r = wrap_near(s_ar[n] + dr[i], H), c = wrap_near(s_ac[n] + dc[i], W);
                 const size_t off = woff + (size_t)r * W + c;
                 // (volatile: past this CU's vector cache, which may hold the line from before the patch)
                 const TO l = __builtin_bit_cast(TO, *reinterpret_cast<const volatile unsigned short*>(oL + off));
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(64) void agents_lookahead_patch(LookaheadArgs A) {
                     const unsigned int w = s_s1[lane][i + 1];
                     double val = 0.0;
                     if ((A.mask >> cand[i]) & 1)
-                        val = (double)(float)(w & 0xffffu) / 1000.0 + (double)(float)(w >> 16) / 1000.0;
+                        val = dw_permille_to_natural((double)(float)(w & 0xffffu)) + dw_permille_to_natural((double)(float)(w >> 16));
                     if (i == 0 || (argmin ? val < bestv : val > bestv)) { best = i; bestv = val; }
                 }
                 a = 4 + best;
@@ -302,8 +302,8 @@ __global__ __launch_bounds__(64) void agents_lookahead_patch(LookaheadArgs A) {
                         if (m == 0) { c -= 1; which = 1; } else if (m == 1) { r -= 1; which = 2; }
                         else if (m == 2) { r += 1; which = 3; } else { c += 1; which = 4; }
                     }
-                    r = ((r % H) + H) % H;
-                    c = ((c % W) + W) % W;
+                    r = wrap_near(r, H);
+                    c = wrap_near(c, W);
                     s_ar[n] = r;
                     s_ac[n] = c;
                     if (a > 4) {
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(64) void agents_lookahead_patch(LookaheadArgs A) {
                         for (int g = 0; g < ng2; ++g) eaten = eaten || (s_gr[g] == r && s_gc[g] == c);
                         if (!eaten) {
                             const unsigned int w = s_s1[n][which];
-                            s += (double)(float)(w & 0xffffu) / 1000.0 + (double)(float)(w >> 16) / 1000.0;
+                            s += dw_permille_to_natural((double)(float)(w & 0xffffu)) + dw_permille_to_natural((double)(float)(w >> 16));
                             s_gr[ng2] = r; s_gc[ng2] = c; ++ng2;
                             const size_t off = woff + (size_t)r * W + c;
                             oL[off] = (TO)0.f;                // the grazed cell (ref :214-216)

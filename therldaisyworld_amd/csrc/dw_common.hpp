@@ -52,7 +52,8 @@ __device__ __forceinline__ float wave_max(float v) {
 typedef _Float16 plane_t;
 __device__ __forceinline__ double to_natural(double x) { return x; }
 __device__ __forceinline__ double to_natural(float k) { return (double)k / 1000.0; }
-__device__ __forceinline__ double to_natural(plane_t k) { return (double)(float)k / 1000.0; }
+// (a binary16 plane holds per-mille INTEGERS: the division-free form is the correctly rounded k / 1000.0, dw_physics.hpp)
+__device__ __forceinline__ double to_natural(plane_t k) { return dw_permille_to_natural((double)(float)k); }
 __device__ __forceinline__ float to_permille(double x) { return (float)(x * 1000.0); }
 __device__ __forceinline__ float to_permille(float k) { return k; }
 __device__ __forceinline__ float to_permille(plane_t k) { return (float)k; }
@@ -72,6 +73,11 @@ __device__ __forceinline__ void stream_store4(plane_t* p, const float4& v) {
     t.y = __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_pkrtz(v.z, v.w));
     __builtin_nontemporal_store(t, reinterpret_cast<dw_u32x2*>(p));
 }
+
+// a coordinate at most one period outside [0, n) back onto the torus (agents move by one cell, stencils reach two)
+__device__ __forceinline__ int wrap_near(int v, int n) { return v < 0 ? v + n : (v >= n ? v - n : v); }
+// ... at most TWO periods outside (a repair reaches four rows beyond a strip of a world that may be only three rows tall)
+__device__ __forceinline__ int wrap_near2(int v, int n) { return wrap_near(wrap_near(v, n), n); }
 
 template <typename T>
 __device__ __forceinline__ void gather9(const T* __restrict__ plane, int H, int W, int r, int c,

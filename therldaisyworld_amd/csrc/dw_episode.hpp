@@ -86,7 +86,7 @@ __device__ __forceinline__ void ep_update_agents(double* ast, int* aidx, const i
             aidx[2 * n + 1] = c;
             if (a > 4) {
                 const int o = r * W + c;
-                s += (double)curL[o] / 1000.0 + (double)curD[o] / 1000.0;
+                s += dw_permille_to_natural((double)curL[o]) + dw_permille_to_natural((double)curD[o]);
                 curL[o] = 0.f;
                 curD[o] = 0.f;
                 ast[n] = s;
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) void episode_small(EpisodeIO io, int B, int N,
                         double v = 0.0;
                         if ((obs_mask >> k) & 1) {
                             const int r = (ar + (k / 3 - 1) + H) % H, c = (ac + (k % 3 - 1) + W) % W;
-                            v = (double)curL[r * W + c] / 1000.0 + (double)curD[r * W + c] / 1000.0;
+                            v = dw_permille_to_natural((double)curL[r * W + c]) + dw_permille_to_natural((double)curD[r * W + c]);
                         }
                         if (i == 0 || (argmin ? v < bestv : v > bestv)) { best = i; bestv = v; }
                     }
@@ -400,19 +400,19 @@ __global__ __launch_bounds__(256) void episode_mlp(EpisodeMlpIO io, int B, int N
                 for (int a = 0; a < 3; ++a)
 #pragma unroll
                     for (int e = 0; e < 3; ++e) {
-                        l9[a * 3 + e] = (double)nxtL[rows[a] * W + cols[e]] / 1000.0;
-                        d9[a * 3 + e] = (double)nxtD[rows[a] * W + cols[e]] / 1000.0;
+                        l9[a * 3 + e] = dw_permille_to_natural((double)nxtL[rows[a] * W + cols[e]]);
+                        d9[a * 3 + e] = dw_permille_to_natural((double)nxtD[rows[a] * W + cols[e]]);
                     }
                 const CellF64 o = cell_f64(Qp, l9, d9);
-                double v4 = dw_round3_k(o.Tl) / 1000.0;
+                double v4 = dw_div1000(dw_round3_k(o.Tl));
                 for (int a = 0; a < N; ++a)                       // ref forward :454-459: agent states stamped, last wins
                     if (aidx[2 * a] == r && aidx[2 * a + 1] == c) v4 = ast[a];
-                x[0 * 9 + k] = dw_round3_k(Qp.p - o.nl - o.nd) / 1000.0;
-                x[1 * 9 + k] = (double)curL[r * W + c] / 1000.0;
-                x[2 * 9 + k] = (double)curD[r * W + c] / 1000.0;
-                x[3 * 9 + k] = dw_round3_k(o.T) / 1000.0;
+                x[0 * 9 + k] = dw_div1000(dw_round3_k(Qp.p - o.nl - o.nd));
+                x[1 * 9 + k] = dw_permille_to_natural((double)curL[r * W + c]);
+                x[2 * 9 + k] = dw_permille_to_natural((double)curD[r * W + c]);
+                x[3 * 9 + k] = dw_div1000(dw_round3_k(o.T));
                 x[4 * 9 + k] = v4;
-                x[5 * 9 + k] = dw_round3_k(o.Td) / 1000.0;
+                x[5 * 9 + k] = dw_div1000(dw_round3_k(o.Td));
                 x[6 * 9 + k] = 0.0;
             }
         }

@@ -38,12 +38,12 @@ __global__ __launch_bounds__(256) void materialise(const PrevT* __restrict__ pL,
     if (grid7) {
         double* g = grid7 + (size_t)b * 7 * n + cell;
         if (POST) {
-            g[0 * n] = dw_round3_k(P.p - o.nl - o.nd) / 1000.0;
+            g[0 * n] = dw_div1000(dw_round3_k(P.p - o.nl - o.nd));
             g[1 * n] = to_natural(cL[woff + cell]);
             g[2 * n] = to_natural(cD[woff + cell]);
-            g[3 * n] = dw_round3_k(o.T) / 1000.0;
-            g[4 * n] = dw_round3_k(o.Tl) / 1000.0;
-            g[5 * n] = dw_round3_k(o.Td) / 1000.0;
+            g[3 * n] = dw_div1000(dw_round3_k(o.T));
+            g[4 * n] = dw_div1000(dw_round3_k(o.Tl));
+            g[5 * n] = dw_div1000(dw_round3_k(o.Td));
         } else {
             g[0 * n] = P.p - l9[4] - d9[4];
             g[1 * n] = l9[4];

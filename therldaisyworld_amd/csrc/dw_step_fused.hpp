@@ -42,7 +42,7 @@ struct FusedGeom {
 template <typename TI>
 __device__ inline unsigned int exact1_word(const TI* __restrict__ pL, const TI* __restrict__ pD, int H, int W,
                                            int r, int c, const PhysF64& Pa) {
-    const int rr = ((r % H) + H) % H, cc = ((c % W) + W) % W;
+    const int rr = wrap_near2(r, H), cc = wrap_near2(c, W);    // (callers pass in-range coordinates +- 4, H >= 3: no division)
     const int ru = rr == 0 ? H - 1 : rr - 1, rd = rr == H - 1 ? 0 : rr + 1;
     const int cl = cc == 0 ? W - 1 : cc - 1, cr = cc == W - 1 ? 0 : cc + 1;
     const int rows[3] = {ru, rr, rd}, cols[3] = {cl, cc, cr};
