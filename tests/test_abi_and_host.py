@@ -369,3 +369,18 @@ def test_division_free_permille_quotient_is_exact_below_2_pow_22(tmp_path):
     exe = tmp_path / "chk"
     subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-o", str(exe), str(src), "-lm"])
     assert subprocess.check_output([str(exe)]).strip() == b"0"
+
+
+def test_ft_convolve_refuses_what_it_does_not_implement_before_touching_a_device():
+    """therldaisyworld_amd.nn.functional.ft_convolve (ref daisy/nn/functional.py:12-49): argument checks run on the host,
+    before an engine is created - a grid that is not (B, C, H, W), a kernel that is not 3x3 (the reference's un-padded
+    branch), a grid below 3x3.  (The device results are pinned by fixture G6 in tests/test_gpu_round4.py.)"""
+    from therldaisyworld_amd.nn.functional import ft_convolve, make_neighborhood
+    k = np.ones((1, 1, 3, 3))
+    with pytest.raises(ValueError):
+        ft_convolve(np.zeros((4, 8, 8)), k)
+    with pytest.raises(ValueError):
+        ft_convolve(np.zeros((2, 1, 8, 8)), np.ones((1, 1, 8, 8)))
+    with pytest.raises(ValueError):
+        ft_convolve(np.zeros((2, 1, 2, 8)), k)
+    assert make_neighborhood(1, "von_neumann").tolist() == [[0, 1, 0], [1, 1, 1], [0, 1, 0]]
