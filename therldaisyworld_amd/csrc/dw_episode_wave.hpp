@@ -137,27 +137,44 @@ __device__ __forceinline__ EwReach ew_reach(const float2* pc, int ar, int ac, in
 }
 
 // update_agents (ref :181-244, collision_mode 0) with the agents as LANES (lane n = agent n; action a in 0..8): decay,
-// move, "the first agent to graze a cell eats it all" resolved with N wave-uniform v_readlane pairs, grazed cells
-// zeroed, clip - straight-line select code for every lane (lanes without an agent are masked by is_agent).
+// move, "the first agent to graze a cell eats it all" resolved with one wave-uniform v_readlane + v_cmp (a lane mask) per
+// agent, grazed cells zeroed, clip - straight-line select code for every lane (lanes without an agent are masked by
+// is_agent).
 __device__ __forceinline__ void ew_update_agents(int a, const EwReach& R, bool is_agent, int lane, int N, int W,
                                                  double agent_gamma, double& ast, int& ar, int& ac, float2* pc) {
     const double s0 = ast - agent_gamma;
     const bool alive = is_agent && s0 > 0.0;
     const int m = a & 3;
     const bool stay = a == 8;
-    const double gain = stay ? R.nat_own : (m == 0 ? R.nat0 : (m == 1 ? R.nat1 : (m == 2 ? R.nat2 : R.nat3)));
-    const int nr = stay ? ar : (m == 1 ? R.rU : (m == 2 ? R.rD : ar));
-    const int nc = stay ? ac : (m == 0 ? R.cL : (m == 3 ? R.cR : ac));
+    // (one select after the other: a nested conditional on m becomes a switch, i.e. a tree of exec-mask branches)
+    // (values first: selecting between loads of R's members gets sunk into one load from a selected address, which
+    // keeps R in scratch memory)
+    const double n0 = R.nat0, n1 = R.nat1, n2 = R.nat2, n3 = R.nat3, n_own = R.nat_own;
+    const int rU = R.rU, rD = R.rD, cL = R.cL, cR = R.cR;
+    double gain = n0;
+    gain = m == 1 ? n1 : gain;
+    gain = m == 2 ? n2 : gain;
+    gain = m == 3 ? n3 : gain;
+    gain = stay ? n_own : gain;
+    int nr = ar, nc = ac;
+    nr = m == 1 ? rU : nr;
+    nr = m == 2 ? rD : nr;
+    nc = m == 0 ? cL : nc;
+    nc = m == 3 ? cR : nc;
+    nr = stay ? ar : nr;
+    nc = stay ? ac : nc;
     ar = alive ? nr : ar;
     ac = alive ? nc : ac;
     const bool graze = alive && a > 4;
     const int o = ar * W + ac;
-    bool first = true;                                           // no earlier agent grazes my cell
+    // "an earlier agent grazes my cell" as lane masks: one v_readlane + one v_cmp (whose result IS the mask) per agent
+    const int key = graze ? o : -1;                              // an agent that does not graze matches no cell
+    unsigned long long beaten = 0ull;
     for (int mm = 0; mm < N; ++mm) {                             // wave-uniform
-        const int om = __builtin_amdgcn_readlane(o, mm);
-        const int gm = __builtin_amdgcn_readlane((int)graze, mm);
-        first = first && !(gm && mm < lane && om == o);
+        const int km = __builtin_amdgcn_readlane(key, mm);
+        beaten |= __builtin_amdgcn_ballot_w64(km == o) & (~1ull << mm);      // lanes above mm on mm's cell
     }
+    const bool first = ((beaten >> lane) & 1ull) == 0ull;
     const double s1 = (graze && first) ? s0 + gain : s0;
     if (is_agent) ast = s1 < 0.0 ? 0.0 : (s1 > 1.0 ? 1.0 : s1);
     if (graze) pc[o] = make_float2(0.f, 0.f);                   // (every read of the step precedes it in program order)
@@ -259,11 +276,16 @@ __global__ __launch_bounds__(256) void episode_wave(EpisodeWaveArgs A) {
                 // first maximum / minimum over the (masked) candidates, as np.argmax / np.argmin
                 const double v0 = ((obs_mask >> 3) & 1) ? R.nat0 : 0.0, v1 = ((obs_mask >> 1) & 1) ? R.nat1 : 0.0;
                 const double v2 = ((obs_mask >> 7) & 1) ? R.nat2 : 0.0, v3 = ((obs_mask >> 5) & 1) ? R.nat3 : 0.0;
+                // (np.argmin = the first maximum of the negated values: one sign flip per candidate - covers are never
+                // NaN, and -0.0 compares equal to 0.0 - instead of both comparisons and a select at every level)
+                const unsigned long long flip = argmin ? 0x8000000000000000ull : 0ull;
+                const double w0 = __longlong_as_double(__double_as_longlong(v0) ^ flip), w1 = __longlong_as_double(__double_as_longlong(v1) ^ flip);
+                const double w2 = __longlong_as_double(__double_as_longlong(v2) ^ flip), w3 = __longlong_as_double(__double_as_longlong(v3) ^ flip);
                 int best = 0;
-                double bestv = v0;
-                { const bool bt = argmin ? v1 < bestv : v1 > bestv; best = bt ? 1 : best; bestv = bt ? v1 : bestv; }
-                { const bool bt = argmin ? v2 < bestv : v2 > bestv; best = bt ? 2 : best; bestv = bt ? v2 : bestv; }
-                { const bool bt = argmin ? v3 < bestv : v3 > bestv; best = bt ? 3 : best; }
+                double bestv = w0;
+                { const bool bt = w1 > bestv; best = bt ? 1 : best; bestv = bt ? w1 : bestv; }
+                { const bool bt = w2 > bestv; best = bt ? 2 : best; bestv = bt ? w2 : bestv; }
+                { const bool bt = w3 > bestv; best = bt ? 3 : best; }
                 const int a = greedy ? 4 + best : (from_table ? tab : 0);
                 if (t0 + ts == K - 1 && is_agent && io.action) io.action[(size_t)b * N + lane] = a;
                 ew_update_agents(a, R, is_agent, lane, N, W, agent_gamma, ast, ar, ac, pc);
