@@ -248,8 +248,11 @@ def _population_chunk(acc, rewards, dones, half, worlds_per_member):
     run_t = running[None, :] & ~earlier                                            # running DURING step t
     none_left = np.nonzero(~(run_t & ~all_done).any(axis=1))[0]
     executed = int(none_left[0]) + 1 if none_left.size else K
-    live = np.repeat(run_t[:executed], worlds_per_member, axis=1)[:, :, None, None]
-    alive = np.count_nonzero(live & ~dones[:executed], axis=0)                     # = sum(live * (1 - done)): integers, any order
+    if run_t[:executed].all():                                                     # the usual chunk: every member still runs
+        alive = executed - np.count_nonzero(dones[:executed], axis=0)              # = sum(1 - done): integers, any order
+    else:
+        live = np.repeat(run_t[:executed], worlds_per_member, axis=1)[:, :, None, None]
+        alive = np.count_nonzero(live & ~dones[:executed], axis=0)                 # = sum(live * (1 - done))
     acc["done_at"][...] += alive
     acc["total_steps"][...] += alive
     # one member's mean of one step = the reference's `reward[:, :half].mean()` on that member's block of worlds
