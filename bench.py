@@ -245,7 +245,9 @@ def main():
     if os.environ.get("DW_BENCH_ALL_RANKS_ON_DEVICE0"):     # rehearsal of the N > 1 path on a 1-GPU box
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    dist = ensemble.init_process_group(args.backend, device=local_rank) if world > 1 else None
+    # (DW_DIST_FORCE_COLLECTIVES=1: a one-rank group anyway - every collective of the run on RCCL, on a 1-GPU box)
+    force_group = os.environ.get("DW_DIST_FORCE_COLLECTIVES", "0") == "1"
+    dist = ensemble.init_process_group(args.backend, device=local_rank) if (world > 1 or force_group) else None
 
     import therldaisyworld_amd as amd
     from therldaisyworld_amd import _ffi

@@ -65,3 +65,21 @@ def test_bench_agent_workload_and_self_launched_ranks():
     assert d2["n_gpus"] == 2 and d2["config"]["total_worlds"] == 128 and d2["cpu_baseline"] is None
     assert d2["rccl"]["backend"] == "gloo" and d2["rccl"]["world_size"] == 2 and d2["rccl"]["ranks_reporting"] == [0, 1]
     assert len(d2["per_rank_value"]) == 2 and sum(d2["per_rank_value"]) >= d2["value"] * 0.999
+
+
+def test_bench_through_a_one_rank_rccl_group():
+    """The N > 1 path's collectives on RCCL itself: a 1-GPU box cannot hold two nccl ranks, but a ONE-rank nccl group can be
+    made to run every collective of a run (DW_DIST_FORCE_COLLECTIVES=1: rendezvous, communicator bound to the device,
+    the MIN / MAX all-reduces on float64, the all-gathers of int64 / float64 / padded uint8 per-world statistics,
+    barriers, destroy) - device tensors, dtypes and the library's version string as the 8-GPU run will use them."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env.update(DW_DIST_FORCE_COLLECTIVES="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--backend", "nccl", "--workload", "c2", "--worlds", "64",
+                        "--steps", "16", "--warmup", "4", "--preheat-s", "0.1", "--no-cpu-baseline", "--no-modes",
+                        "--no-workloads"], capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["n_gpus"] == 1 and d["config"]["total_worlds"] == 64
+    assert d["rccl"]["backend"] == "nccl" and d["rccl"]["world_size"] == 1 and d["rccl"]["ranks_reporting"] == [0]
+    assert d["rccl"]["nccl_version"]                        # RCCL answered for itself
+    assert len(d["per_rank_value"]) == 1 and d["per_rank_value"][0] >= d["value"] * 0.999

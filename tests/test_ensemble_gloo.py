@@ -83,3 +83,40 @@ def test_gather_over_gloo_world_size_2(tmp_path):
     for rank, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {rank} failed:\n{out}"
         assert f"rank {rank} ok" in out
+
+
+ONE_RANK = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.environ["DW_ROOT"])
+from therldaisyworld_amd import ensemble
+dist = ensemble.init_process_group("gloo")
+assert dist is not None and dist.get_world_size() == 1
+x = (np.arange(12, dtype=np.int32).reshape(3, 4) * 7)
+assert np.array_equal(ensemble.gather_per_world(x, counts=[3]), x)
+assert ensemble.max_over_ranks(2.5) == 2.5 and ensemble.agree_on_worlds(37) == 37
+assert ensemble.gather_scalars(1.25) == [1.25]
+g = ensemble.describe_group()
+assert g["backend"] == "gloo" and g["world_size"] == 1 and g["ranks_reporting"] == [0], g
+dist.barrier()
+dist.destroy_process_group()
+print("one-rank ok")
+"""
+
+
+def test_one_rank_group_runs_the_collectives_when_forced():
+    """DW_DIST_FORCE_COLLECTIVES=1 (the GPU box's rehearsal of the RCCL path, tests/test_bench_contract.py): a group of one
+    rank is created and every helper goes through its collective instead of short-circuiting."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env.update(DW_ROOT=ROOT, DW_DIST_FORCE_COLLECTIVES="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    p = subprocess.run([sys.executable, "-c", ONE_RANK], capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 0 and "one-rank ok" in p.stdout, p.stderr[-2000:]
+    # without the switch a single process makes no group at all
+    env.pop("DW_DIST_FORCE_COLLECTIVES")
+    p = subprocess.run([sys.executable, "-c", "import os, sys; sys.path.insert(0, os.environ['DW_ROOT']); "
+                        "from therldaisyworld_amd import ensemble; assert ensemble.init_process_group('gloo') is None; "
+                        "assert ensemble.describe_group()['backend'] is None"], capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]

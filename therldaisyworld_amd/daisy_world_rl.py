@@ -286,8 +286,12 @@ class RLDaisyWorld:
         B, d = self.batch_size, self.dim
         dark_probability = np.random.rand(B, 2, d, d)
         light_probability = np.random.rand(B, 2, d, d)
-        dark = 1.0 * (dark_probability[:, 0] < self.dark_proportion) * self.initial_ad * dark_probability[:, 1]
-        light = 1.0 * (light_probability[:, 0] < self.light_proportion) * self.initial_al * light_probability[:, 1]
+        # ref: 1.0 * (p[:, 0] < proportion) * initial * p[:, 1] - the same products (multiplication commutes, the mask is
+        # exactly 0 or 1) in two passes instead of four
+        dark = np.multiply(dark_probability[:, 1], self.initial_ad)
+        dark *= dark_probability[:, 0] < self.dark_proportion
+        light = np.multiply(light_probability[:, 1], self.initial_al)
+        light *= light_probability[:, 0] < self.light_proportion
         return light, dark
 
     def initialize_grid(self):

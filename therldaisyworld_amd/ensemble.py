@@ -43,8 +43,11 @@ def init_process_group(backend: str | None = None, device: int | None = None, ti
     import torch
     import torch.distributed as dist
     rank, local_rank, world = rank_info()
-    if world == 1:
+    if world == 1 and os.environ.get("DW_DIST_FORCE_COLLECTIVES", "0") != "1":
         return None
+    if world == 1:                                            # the one-rank rehearsal (see _no_group)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
     if not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
@@ -204,13 +207,23 @@ def launch_ranks(script: str, argv, n_ranks: int, rank_timeout_s: float = 300.0,
     return code
 
 
+def _no_group() -> bool:
+    """True when there is nothing to communicate with: no process group, or a group of one rank - unless
+    DW_DIST_FORCE_COLLECTIVES=1 asks for the collectives anyway (the GPU rehearsal of the RCCL path on a 1-GPU box:
+    every collective of a run on a one-rank nccl group, tests/test_gpu_round4.py)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return True
+    return dist.get_world_size() == 1 and os.environ.get("DW_DIST_FORCE_COLLECTIVES", "0") != "1"
+
+
 def gather_per_world(local: np.ndarray, counts=None, device=None) -> np.ndarray:
     """Concatenate per-world arrays (leading axis = this rank's worlds) from all ranks, in rank
     order, on every rank.  Ragged shards are handled by padding to the largest shard."""
     import torch
     import torch.distributed as dist
     local = np.ascontiguousarray(local)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if _no_group():
         return local.copy()
     world = dist.get_world_size()
     if device is None:
@@ -239,7 +252,7 @@ def gather_per_world(local: np.ndarray, counts=None, device=None) -> np.ndarray:
 def max_over_ranks(value: float, device=None) -> float:
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if _no_group():
         return float(value)
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else "cpu"
@@ -283,7 +296,7 @@ def gather_scalars(value: float, device=None) -> list:
     """One float per rank, in rank order, on every rank."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if _no_group():
         return [float(value)]
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else "cpu"
