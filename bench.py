@@ -34,6 +34,10 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with these extra
                fraction from the committed SQ counters; `bound` is what those counters say.  `copy_ceiling` =
                what a plain device copy reaches on this card, measured live (the practical ceiling
                beside the spec peak), `measured_over_copy_ceiling` = the kernel's measured HBM rate / that.
+  power        {"board_w", "limit_w", "sclk_mhz", "samples"}: the board's power and engine clock read with rocm-smi beside an
+               UNTIMED extra pass of the same launches after the timed region (N = 1, data-parallel workloads; null when
+               rocm-smi cannot be read).  At the north-star shape the step-pair kernels hold the card at its package power
+               limit and the engine clock is what the power manager leaves (profiles/r04_power_trace.txt).
   cpu_baseline the oracle's C restatement (oracle/daisy_oracle.c, "port") timed on this host's cores
                on a bounded sample of the same workload (rank 0, N=1 only).
 """
@@ -91,6 +95,7 @@ def parse(argv=None):
                     help="self-launched N > 1 runs: kill every rank and exit 124 when the run takes longer")
     ap.add_argument("--rank-log-dir", default="", help="self-launched N > 1 runs: keep the per-rank logs here")
     ap.add_argument("--no-modes", action="store_true", help="skip the extra run in the other arithmetic mode")
+    ap.add_argument("--no-power", action="store_true", help="skip the untimed extra pass that reads board power / clock")
     ap.add_argument("--no-workloads", action="store_true", help="skip the extra measurements of c2 ... c5")
     ap.add_argument("--selftest-spawn", action="store_true",
                     help="CPU rehearsal of the N > 1 plumbing (rank launch, rendezvous, barrier, max-over-ranks, "
@@ -278,7 +283,48 @@ def main():
                     raise
                 B //= 2
 
-    def measure(workload, precision, steps, warmup, preheat_s, worlds=0):
+    def board_power_while(work, settle_s=0.45, samples=3):
+        """Board power and engine clock WHILE `work()` (a blocking library call: ctypes releases the GIL) runs on a helper
+        thread - rocm-smi read beside it, after `settle_s` (the power manager needs a few hundred ms to reach its steady
+        state).  An untimed extra pass after the timed region; every failure (no rocm-smi, unexpected output) gives None."""
+        import re
+        import shutil
+        import subprocess
+        import threading
+        smi = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+        err = []
+
+        def guarded():
+            try:
+                work()
+            except Exception as e:                      # (reported in the object instead of a traceback on a helper thread)
+                err.append(f"work: {type(e).__name__}: {e}")
+
+        th = threading.Thread(target=guarded)
+        got = []
+        t_start = time.perf_counter()
+        th.start()
+        try:
+            time.sleep(settle_s)
+            while th.is_alive() and len(got) < samples:
+                txt = subprocess.run([smi, "-d", str(local_rank), "--showpower", "--showclocks", "--showmaxpower"],
+                                     capture_output=True, text=True, timeout=20).stdout
+                w = re.search(r"Current Socket Graphics Package Power \(W\): *([0-9.]+)", txt) or \
+                    re.search(r"Average Graphics Package Power \(W\): *([0-9.]+)", txt)
+                c = re.search(r"sclk clock level: *\S+ *\((\d+)Mhz\)", txt)
+                mx = re.search(r"Max Graphics Package Power \(W\): *([0-9.]+)", txt)
+                if w and c and th.is_alive():           # (a sample that ended after the work did is not one of it)
+                    got.append((float(w.group(1)), int(c.group(1)), float(mx.group(1)) if mx else None))
+        except Exception as e:
+            err.append(f"rocm-smi: {type(e).__name__}: {e}")
+        th.join()
+        if not got:
+            return {"board_w": None, "error": "; ".join(err) or f"no sample while the work ran ({time.perf_counter() - t_start:.2f} s)"}
+        return {"board_w": max(g[0] for g in got), "limit_w": got[0][2], "sclk_mhz": sorted(g[1] for g in got)[len(got) // 2],
+                "samples": [[g[0], g[1]] for g in got], "busy_s": round(time.perf_counter() - t_start, 2),
+                "source": "rocm-smi --showpower --showclocks beside an untimed extra pass of the same launches"}
+
+    def measure(workload, precision, steps, warmup, preheat_s, worlds=0, power=False):
         """One timed run of `steps` steps of `workload` in the given arithmetic mode."""
         B, G, N, desc = WORKLOADS[workload]
         if worlds:
@@ -364,11 +410,18 @@ def main():
         fused_ms, fused_n, elem_bytes = eng.last_step_n_timing() if N == 0 else (0.0, 0, 2)
         stats = eng.reduce()
         info = eng.kernel_info()
-        res = {"workload": workload, "desc": desc, "precision": precision, "B": B, "G": G, "N": N, "cells": cells,
+        fixups = eng.last_fixup_count()
+        pw = None
+        if power and N == 0:
+            # ~2 s more of the same launches at the luminosity reached, untimed (everything the line reports was read
+            # above), with the board's power and engine clock read beside them
+            extra = int(min(max(2.0 / max(elapsed / steps, 1e-6), 8), 20000))
+            pw = board_power_while(lambda: (run(extra + (extra & 1), L, 0.0), eng.sync()))   # (dw_step_n only enqueues)
+        res = {"workload": workload, "power": pw, "desc": desc, "precision": precision, "B": B, "G": G, "N": N, "cells": cells,
                "value": cells * steps * n_gpus / elapsed, "ms_per_step": elapsed / steps * 1e3,
                "rank_value": cells * steps / own_elapsed,
                "event_ms_per_step": ev_ms / steps, "fused_ms": fused_ms, "fused_launches": fused_n,
-               "plane_elem_bytes": elem_bytes, "fixups": eng.last_fixup_count(), "kernel": info, "stats": stats,
+               "plane_elem_bytes": elem_bytes, "fixups": fixups, "kernel": info, "stats": stats,
                "preheat_s": preheat, "preheat_steps": pre_steps}
         eng.close()
         return res
@@ -446,7 +499,8 @@ def main():
                                                                      "bytes_per_cell_update", "launch_ms", "launches_timed",
                                                                      "steps_per_launch")}}
 
-    m = measure(args.workload, args.precision, args.steps, args.warmup, args.preheat_s, args.worlds)
+    m = measure(args.workload, args.precision, args.steps, args.warmup, args.preheat_s, args.worlds,
+                power=rank == 0 and n_gpus == 1 and not args.no_power)
     all_stats = ensemble.gather_per_world(m["stats"]) if dist is not None else m["stats"]   # end-of-run gather (RCCL)
     group = ensemble.describe_group()                       # backend, world size, RCCL version, ranks that answered
     per_rank = ensemble.gather_scalars(m["rank_value"])     # each rank's own cell-updates/s over ITS elapsed time
@@ -475,6 +529,7 @@ def main():
                    "parallelism": f"ensemble shard x{n_gpus} (no data-path collective)"},
         "roofline": roofline(m),
         "preheat_s": round(m["preheat_s"], 3),
+        "power": m["power"],                             # board W / limit / engine clock while the kernels run (or null)
         "rccl": group,
         "per_rank_value": per_rank,
     }

@@ -49,6 +49,9 @@ def test_bench_line_follows_the_contract():
     # what ran: a single process has no collective backend; its own throughput is the whole job's
     assert d["rccl"] == {"backend": None, "world_size": 1, "nccl_version": None, "ranks_reporting": [0]}
     assert len(d["per_rank_value"]) == 1 and d["per_rank_value"][0] >= d["value"] * 0.999
+    # board power / engine clock read beside an untimed extra pass of the same launches (null when rocm-smi cannot be read)
+    pw = d["power"]
+    assert pw["board_w"] is None or (50.0 < pw["board_w"] < 2000.0 and 100 <= pw["sclk_mhz"] <= 3000 and pw["samples"])
 
 
 def test_bench_agent_workload_and_self_launched_ranks():

@@ -6,15 +6,15 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 : > "$OUT"
 sample() {   # <label> <pid>
   while kill -0 "$2" 2>/dev/null; do
-    p=$(rocm-smi --showpower 2>/dev/null | grep -i -m1 "power" | sed 's/.*: *//')
+    p=$(rocm-smi --showpower 2>/dev/null | grep -m1 "(W)" | sed 's/.*: *//')
     c=$(rocm-smi --showclocks 2>/dev/null | grep -i -m1 "sclk" | sed 's/.*: *//')
     echo "$1 $(date +%s.%N | cut -c1-14) power: $p | sclk: $c" >> "$OUT"
     sleep 0.4
   done
 }
-for spec in "target fast 240" "target exact 180" "c2 fast 20000" "c2 exact 15000"; do
+for spec in "target fast 240" "target exact 180" "c2 fast 512" "c2 exact 512" "c2 fast 512" "c2 exact 512"; do
   set -- $spec
-  python3 "$R/bench.py" --workload $1 --precision $2 --steps $3 --warmup 4 --no-cpu-baseline --no-modes --no-workloads --preheat-s 0.3 \
+  python3 "$R/bench.py" --workload $1 --precision $2 --steps $3 --warmup 4 --no-cpu-baseline --no-modes --no-workloads --no-power --preheat-s 0.3 \
       > "$OUT.$1.$2.json" 2> /dev/null &
   pid=$!
   sample "$1/$2" $pid

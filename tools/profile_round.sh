@@ -13,7 +13,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_${TAG}_${WL}
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-COMMON="--workload $WL --warmup 4 --no-cpu-baseline --no-modes --no-workloads --preheat-s 0.3"
+COMMON="--workload $WL --warmup 4 --no-cpu-baseline --no-modes --no-workloads --no-power --preheat-s 0.3"
 for prec in exact fast; do
   rocprofv3 --kernel-trace --stats -d "$OUT/stats_$prec" -o s --output-format csv -- \
       python3 "$R/bench.py" $COMMON --steps $((STEPS * 3)) --preheat-s 1.5 --precision $prec \
