@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define DW_ABI_VERSION 4
+#define DW_ABI_VERSION 5
 
 /* ---- error codes ---------------------------------------------------------------------------- */
 enum {
@@ -340,8 +340,15 @@ int dw_run_episode_mlp(dw_handle* h, int32_t nsteps, const double* L_schedule, c
  * (notebooks/greedy_longevity_abatement.ipynb cell 2:28-57: stop as soon as every world is dead) would
  * have executed — without moving the state over PCIe.  Costs up to two extra copies of the two planes
  * in HBM, allocated at the first save. */
-int dw_snapshot_save(dw_handle* h);
+int dw_snapshot_save(dw_handle* h);               /* = slot 0 */
 int dw_snapshot_restore(dw_handle* h);
+/* Two slots (ABI 5): a harness that lets the device run chunk c + 1 while the host still accounts for chunk c
+ * (therldaisyworld_amd/harness.py, the ES fitness episodes: ref daisy/evo/sges.py:144-181) saves the start of chunk c in
+ * slot c % 2 - when chunk c turns out to end the episode, the state at its start is still there although chunk c + 1 has
+ * saved its own.  A save is one kernel launch for all regions of the state. */
+#define DW_SNAPSHOT_SLOTS 2
+int dw_snapshot_save_slot(dw_handle* h, int32_t slot);
+int dw_snapshot_restore_slot(dw_handle* h, int32_t slot);
 
 /* Device-resident lifespan harness (ref notebooks/greedy_longevity_abatement.ipynb cell 2:28-57):
  * accumulate done_at[b] += (max_k > threshold_k) and agents_done_at[b][n] += !(done) after each

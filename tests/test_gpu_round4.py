@@ -143,3 +143,46 @@ def test_shrunk_repair_queues_in_every_kernel_family(amd, monkeypatch, family, q
         assert np.array_equal(s["sum_light_k"], _k(light).sum(axis=(1, 2)))
         assert np.array_equal(s["sum_dark_k"], _k(dark).sum(axis=(1, 2)))
     eng.close()
+
+
+@pytest.mark.parametrize("B,H,W,N", [(4, 16, 16, 3), (1, 5, 7, 2), (3, 64, 260, 0)])
+def test_two_snapshot_slots_are_independent(amd, B, H, W, N):
+    """dw_snapshot_save_slot / dw_snapshot_restore_slot (ABI 5): two states saved at different steps come back as they
+    were, in either order, whatever ran in between (one copy launch per save; 1 x 5 x 7: planes of 70 bytes, the byte
+    tail of the copy kernel)."""
+    from therldaisyworld_amd import _ffi
+    p = amd.default_params(B, H, W, N)
+    p.precision = _ffi.PRECISION["exact"]
+    eng = amd.Engine(p)
+    eng.init_random(11)
+    act = np.zeros((B, N, 1), dtype=int) if N else None
+    eng.step(0.9, act)
+
+    def state():
+        out = [*eng.download_planes(), eng.reduce().tobytes()]
+        if N:
+            out += [*eng.download_agents(), eng.get_obs()]
+        return out
+
+    with pytest.raises(_ffi.DaisyHipError):
+        eng.snapshot_restore(1)                              # nothing saved in that slot yet
+    with pytest.raises(_ffi.DaisyHipError):
+        eng.snapshot_save(2)                                 # two slots
+    a = state()
+    eng.snapshot_save(0)
+    eng.step(0.95, act)
+    eng.step(1.0, act)
+    b = state()
+    eng.snapshot_save(1)
+    eng.step_n(3, 1.2, 0.0, 0.75, 1.5) if not N else [eng.step(1.2, act) for _ in range(3)]
+    eng.snapshot_restore(0)
+    for x, y in zip(a, state()):
+        assert np.array_equal(x, y)
+    eng.step(1.3, act)
+    eng.snapshot_restore(1)
+    for x, y in zip(b, state()):
+        assert np.array_equal(x, y)
+    eng.snapshot_restore(0)                                  # still there
+    for x, y in zip(a, state()):
+        assert np.array_equal(x, y)
+    eng.close()

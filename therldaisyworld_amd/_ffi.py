@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DW_LIB", os.path.join(_HERE, "libdaisyworld_hip.so"))   # DW_LIB: tuning builds
 
-DW_ABI_VERSION = 4
+DW_ABI_VERSION = 5
 DW_OK, DW_EINVAL, DW_ENODEVICE, DW_ENOMEM, DW_EHIP, DW_ESTATE = 0, -1, -2, -3, -4, -5
 PRECISION = {"exact": 0, "fast": 1, "f64": 2}
 STATE_CURRENT, STATE_PREVIOUS = 0, 1
@@ -92,6 +92,8 @@ SIGNATURES = {
     "dw_env_step": (C.c_int, [_vp, _pi, _i32, _i32, _dbl, _pd, _pd, _pu8]),
     "dw_snapshot_save": (C.c_int, [_vp]),
     "dw_snapshot_restore": (C.c_int, [_vp]),
+    "dw_snapshot_save_slot": (C.c_int, [_vp, C.c_int32]),
+    "dw_snapshot_restore_slot": (C.c_int, [_vp, C.c_int32]),
     "dw_lifespan_reset": (C.c_int, [_vp]),
     "dw_lifespan_accumulate": (C.c_int, [_vp, _u32]),
     "dw_lifespan_download": (C.c_int, [_vp, _pi, _pi, _pi]),

@@ -160,18 +160,21 @@ struct dw_handle {
     StatsDev* side_stats = nullptr;   // reductions of dw_forward_f64's side computation (not the handle's)
     unsigned char* pinned = nullptr;  // page-locked host staging of dw_env_step (actions in, obs/reward/done out)
     size_t pinned_bytes = 0;
-    // dw_snapshot_save / dw_snapshot_restore: device copy of the current state
-    plane_t* snapL = nullptr;
-    plane_t* snapD = nullptr;
-    plane_t* snapPL = nullptr;        // the retained previous state (observations, caches) when there is one
-    plane_t* snapPD = nullptr;
-    bool snap_stepped = false;
-    double snap_L_last = 0.0;
-    UnqOwner snap_unq = OWN_NONE;
-    int* snap_idx = nullptr;
-    double* snap_st = nullptr;
-    unsigned char* snap_stats = nullptr;
-    bool snap_valid = false, snap_agents = false;
+    // dw_snapshot_save[_slot] / dw_snapshot_restore[_slot]: device copies of the current state (two slots: a harness
+    // that runs chunk c + 1 while it still accounts for chunk c keeps the starts of both)
+    struct Snapshot {
+        plane_t* L = nullptr;
+        plane_t* D = nullptr;
+        plane_t* PL = nullptr;        // the retained previous state (observations, caches) when there is one
+        plane_t* PD = nullptr;
+        bool stepped = false;
+        double L_last = 0.0;
+        UnqOwner unq = OWN_NONE;
+        int* idx = nullptr;
+        double* st = nullptr;
+        unsigned char* stats = nullptr;
+        bool valid = false, agents = false;
+    } snap[DW_SNAPSHOT_SLOTS];
     // kernel selection
     int tcq = 0, rpt = 0;             // 0 => generic
     Geom geom{};
@@ -196,7 +199,8 @@ struct SyncOnExit {
 // nothing refers to them any more if they are big (the north-star shape: 128 GiB)
 static void release_unquantised(dw_handle* h) {
     if (h->unq != OWN_NONE || !h->U32L) return;
-    if (h->snap_valid && h->snap_unq == OWN_PREV) return;        // a snapshot's previous state lives there
+    for (const auto& sn : h->snap)
+        if (sn.valid && sn.unq == OWN_PREV) return;              // a snapshot's previous state lives there
     if (h->cells * 2 * sizeof(float) < ((size_t)1 << 30)) return;
     (void)hipStreamSynchronize(h->stream);
     (void)hipFree(h->U32L); (void)hipFree(h->U32D);
@@ -1007,9 +1011,11 @@ int dw_destroy(dw_handle* h) {
     if (h->pinned) (void)hipHostFree(h->pinned);
     if (h->ep_pinned) (void)hipHostFree(h->ep_pinned);
     (void)hipFree(h->mlp_w);
-    (void)hipFree(h->snapL); (void)hipFree(h->snapD); (void)hipFree(h->snap_idx); (void)hipFree(h->snap_st);
-    (void)hipFree(h->snapPL); (void)hipFree(h->snapPD);
-    (void)hipFree(h->snap_stats);
+    for (auto& sn : h->snap) {
+        (void)hipFree(sn.L); (void)hipFree(sn.D); (void)hipFree(sn.idx); (void)hipFree(sn.st);
+        (void)hipFree(sn.PL); (void)hipFree(sn.PD);
+        (void)hipFree(sn.stats);
+    }
     (void)hipFree(h->agents_done_at); (void)hipFree(h->done_at); (void)hipFree(h->n_alive);
     (void)hipFree(h->stats2[0]); (void)hipFree(h->stats2[1]); (void)hipFree(h->scratch); (void)hipFree(h->ep_buf); (void)hipFree(h->fixq); (void)hipFree(h->redo_tiles);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -1072,7 +1078,7 @@ int dw_upload_state_f64(dw_handle* h, const double* light, const double* dark) {
     h->unq = OWN_CUR;
     h->have_state = true;
     h->stepped = false;
-    h->snap_valid = false;                      // a snapshot's previous state may have lived in these buffers
+    for (auto& sn : h->snap) sn.valid = false;                      // a snapshot's previous state may have lived in these buffers
     int rc = refresh_stats(h);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(h->stream));   // host buffers may be reused by the caller
@@ -1108,7 +1114,7 @@ int dw_upload_state_f32(dw_handle* h, const float* light, const float* dark, int
     }
     h->have_state = true;
     h->stepped = false;
-    h->snap_valid = false;
+    for (auto& sn : h->snap) sn.valid = false;
     int rc = refresh_stats(h);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -1176,7 +1182,7 @@ int dw_init_random(dw_handle* h, uint64_t seed) {
     h->unq = OWN_CUR;
     h->have_state = true;
     h->stepped = false;
-    h->snap_valid = false;
+    for (auto& sn : h->snap) sn.valid = false;
     return DW_OK;                               // (statistics: reduced by the draw itself)
 }
 
@@ -1202,7 +1208,7 @@ int dw_init_random_quantised(dw_handle* h, uint64_t seed) {
     h->unq = OWN_NONE;
     h->have_state = true;
     h->stepped = false;
-    h->snap_valid = false;
+    for (auto& sn : h->snap) sn.valid = false;
     release_unquantised(h);
     return DW_OK;                               // (statistics: reduced by the draw itself)
 }
@@ -2195,75 +2201,126 @@ static int run_episode_impl(dw_handle* h, int32_t nsteps, const double* L_schedu
     return DW_OK;
 }
 
-// ---- device-side snapshot of the current state ----------------------------------------------------
-int dw_snapshot_save(dw_handle* h) {
+// ---- device-side snapshots of the current state ----------------------------------------------------
+// All regions of a snapshot in ONE launch (seven device-to-device copies were seven stream operations: ~55 us in front of
+// every chunk of the fitness harness, whose whole chunk kernel takes 0.5 ms)
+struct CopyJobs {
+    const void* src[8];
+    void* dst[8];
+    unsigned long long bytes[8];
+    int n;
+};
+__global__ __launch_bounds__(256) void copy_regions(CopyJobs J) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x, t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int j = 0; j < J.n; ++j) {
+        const size_t nb = J.bytes[j];
+        // (every region starts at a hipMalloc'ed address: 256-byte aligned)
+        const uint4* s16 = static_cast<const uint4*>(J.src[j]);
+        uint4* d16 = static_cast<uint4*>(J.dst[j]);
+        for (size_t i = t0; i < nb / 16; i += stride) d16[i] = s16[i];
+        const unsigned char* s1 = static_cast<const unsigned char*>(J.src[j]);
+        unsigned char* d1 = static_cast<unsigned char*>(J.dst[j]);
+        for (size_t i = (nb & ~(size_t)15) + t0; i < nb; i += stride) d1[i] = s1[i];      // the last < 16 bytes
+    }
+}
+static int launch_copy_regions(dw_handle* h, const CopyJobs& J) {
+    size_t most = 0;
+    for (int j = 0; j < J.n; ++j) {
+        NEED(((reinterpret_cast<uintptr_t>(J.src[j]) | reinterpret_cast<uintptr_t>(J.dst[j])) & 15) == 0, DW_EINVAL,
+             "snapshot region not 16-byte aligned");
+        most = J.bytes[j] > most ? J.bytes[j] : most;
+    }
+    if (J.n == 0 || most == 0) return DW_OK;
+    size_t blocks = (most / 16 + 255) / 256;
+    blocks = blocks < 1 ? 1 : (blocks > 8192 ? 8192 : blocks);
+    hipLaunchKernelGGL(copy_regions, dim3((unsigned)blocks), dim3(256), 0, h->stream, J);
+    HIPCHK(hipGetLastError());
+    return DW_OK;
+}
+
+int dw_snapshot_save_slot(dw_handle* h, int32_t slot) {
     NEED(h, DW_EINVAL, "null handle");
+    NEED(slot >= 0 && slot < DW_SNAPSHOT_SLOTS, DW_EINVAL, "snapshot slot out of range");
     const dw_params& p = h->prm;
     HIPCHK(hipSetDevice(p.device));
     NEED(h->have_state, DW_ESTATE, "no state uploaded");
     NEED(cur_quantised(h), DW_ESTATE, "the current state is an un-quantised upload; take a step first");
+    dw_handle::Snapshot& sn = h->snap[slot];
     const size_t bn = (size_t)p.batch * p.n_agents;
     const size_t pb = sizeof(plane_t) * h->cells;
-    if (!h->snapL) {
-        HIPCHK(hipMalloc(&h->snapL, pb));
-        HIPCHK(hipMalloc(&h->snapD, pb));
-        HIPCHK(hipMalloc(&h->snap_stats, h->stats_bytes));
+    if (!sn.L) {
+        HIPCHK(hipMalloc(&sn.L, pb));
+        HIPCHK(hipMalloc(&sn.D, pb));
+        HIPCHK(hipMalloc(&sn.stats, h->stats_bytes));
         if (bn) {
-            HIPCHK(hipMalloc(&h->snap_idx, sizeof(int) * 2 * bn));
-            HIPCHK(hipMalloc(&h->snap_st, sizeof(double) * bn));
+            HIPCHK(hipMalloc(&sn.idx, sizeof(int) * 2 * bn));
+            HIPCHK(hipMalloc(&sn.st, sizeof(double) * bn));
         }
     }
-    HIPCHK(hipMemcpyAsync(h->snapL, h->L16[h->cur], pb, hipMemcpyDeviceToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->snapD, h->D16[h->cur], pb, hipMemcpyDeviceToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->snap_stats, h->stats2[h->sp], h->stats_bytes, hipMemcpyDeviceToDevice, h->stream));
+    CopyJobs J;
+    J.n = 0;
+    auto job = [&J](void* dst, const void* src, size_t bytes) { J.dst[J.n] = dst; J.src[J.n] = src; J.bytes[J.n] = bytes; ++J.n; };
+    job(sn.L, h->L16[h->cur], pb);
+    job(sn.D, h->D16[h->cur], pb);
+    job(sn.stats, h->stats2[h->sp], h->stats_bytes);
     // the previous state too: observations (temperature channels) and the temp / beta / growth caches are
     // derived from it, so a replay from the snapshot must see the same one.  An un-quantised previous state
     // (the step after an upload) stays where it is: its buffers are not reused before the next upload, which
     // invalidates the snapshot.
-    h->snap_stepped = h->stepped;
-    h->snap_L_last = h->L_last;
-    h->snap_unq = h->unq;
+    sn.stepped = h->stepped;
+    sn.L_last = h->L_last;
+    sn.unq = h->unq;
     if (h->stepped && h->unq != OWN_PREV) {
-        if (!h->snapPL) {
-            HIPCHK(hipMalloc(&h->snapPL, pb));
-            HIPCHK(hipMalloc(&h->snapPD, pb));
+        if (!sn.PL) {
+            HIPCHK(hipMalloc(&sn.PL, pb));
+            HIPCHK(hipMalloc(&sn.PD, pb));
         }
-        HIPCHK(hipMemcpyAsync(h->snapPL, h->L16[1 - h->cur], pb, hipMemcpyDeviceToDevice, h->stream));
-        HIPCHK(hipMemcpyAsync(h->snapPD, h->D16[1 - h->cur], pb, hipMemcpyDeviceToDevice, h->stream));
+        job(sn.PL, h->L16[1 - h->cur], pb);
+        job(sn.PD, h->D16[1 - h->cur], pb);
     }
-    h->snap_agents = bn && h->have_agents;
-    if (h->snap_agents) {
-        HIPCHK(hipMemcpyAsync(h->snap_idx, h->idx, sizeof(int) * 2 * bn, hipMemcpyDeviceToDevice, h->stream));
-        HIPCHK(hipMemcpyAsync(h->snap_st, h->st, sizeof(double) * bn, hipMemcpyDeviceToDevice, h->stream));
+    sn.agents = bn && h->have_agents;
+    if (sn.agents) {
+        job(sn.idx, h->idx, sizeof(int) * 2 * bn);
+        job(sn.st, h->st, sizeof(double) * bn);
     }
-    h->snap_valid = true;
+    if (int rc = launch_copy_regions(h, J)) return rc;
+    sn.valid = true;
     return DW_OK;
 }
 
-int dw_snapshot_restore(dw_handle* h) {
+int dw_snapshot_restore_slot(dw_handle* h, int32_t slot) {
     NEED(h, DW_EINVAL, "null handle");
+    NEED(slot >= 0 && slot < DW_SNAPSHOT_SLOTS, DW_EINVAL, "snapshot slot out of range");
     const dw_params& p = h->prm;
     HIPCHK(hipSetDevice(p.device));
-    NEED(h->snap_valid, DW_ESTATE, "no snapshot saved (or a later upload / dw_init_random invalidated it)");
+    const dw_handle::Snapshot& sn = h->snap[slot];
+    NEED(sn.valid, DW_ESTATE, "no snapshot saved in this slot (or a later upload / dw_init_random invalidated it)");
     const size_t bn = (size_t)p.batch * p.n_agents;
     const size_t pb = sizeof(plane_t) * h->cells;
-    HIPCHK(hipMemcpyAsync(h->L16[h->cur], h->snapL, pb, hipMemcpyDeviceToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->D16[h->cur], h->snapD, pb, hipMemcpyDeviceToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->stats2[h->sp], h->snap_stats, h->stats_bytes, hipMemcpyDeviceToDevice, h->stream));
+    CopyJobs J;
+    J.n = 0;
+    auto job = [&J](void* dst, const void* src, size_t bytes) { J.dst[J.n] = dst; J.src[J.n] = src; J.bytes[J.n] = bytes; ++J.n; };
+    job(h->L16[h->cur], sn.L, pb);
+    job(h->D16[h->cur], sn.D, pb);
+    job(h->stats2[h->sp], sn.stats, h->stats_bytes);
+    if (sn.agents) {
+        job(h->idx, sn.idx, sizeof(int) * 2 * bn);
+        job(h->st, sn.st, sizeof(double) * bn);
+    }
+    if (sn.stepped && sn.unq != OWN_PREV) {
+        job(h->L16[1 - h->cur], sn.PL, pb);
+        job(h->D16[1 - h->cur], sn.PD, pb);
+    }
+    if (int rc = launch_copy_regions(h, J)) return rc;
     HIPCHK(hipMemsetAsync(h->stats2[1 - h->sp], 0, h->stats_bytes, h->stream));
-    if (h->snap_agents) {
-        HIPCHK(hipMemcpyAsync(h->idx, h->snap_idx, sizeof(int) * 2 * bn, hipMemcpyDeviceToDevice, h->stream));
-        HIPCHK(hipMemcpyAsync(h->st, h->snap_st, sizeof(double) * bn, hipMemcpyDeviceToDevice, h->stream));
-    }
-    if (h->snap_stepped && h->snap_unq != OWN_PREV) {
-        HIPCHK(hipMemcpyAsync(h->L16[1 - h->cur], h->snapPL, pb, hipMemcpyDeviceToDevice, h->stream));
-        HIPCHK(hipMemcpyAsync(h->D16[1 - h->cur], h->snapPD, pb, hipMemcpyDeviceToDevice, h->stream));
-    }
-    h->unq = h->snap_unq;                       // OWN_PREV: the un-quantised initial state is still in its buffers
-    h->stepped = h->snap_stepped;
-    h->L_last = h->snap_L_last;
+    h->unq = sn.unq;                            // OWN_PREV: the un-quantised initial state is still in its buffers
+    h->stepped = sn.stepped;
+    h->L_last = sn.L_last;
     return DW_OK;
 }
+
+int dw_snapshot_save(dw_handle* h) { return dw_snapshot_save_slot(h, 0); }
+int dw_snapshot_restore(dw_handle* h) { return dw_snapshot_restore_slot(h, 0); }
 
 // ---- plumbing ---------------------------------------------------------------------------------
 

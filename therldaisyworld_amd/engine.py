@@ -54,9 +54,9 @@ class Engine:
         if getattr(self, "_h", None) is not None and self._h:
             self._lib.dw_destroy(self._h)
             self._h = C.c_void_p()
-        if getattr(self, "_pinned", None) is not None:          # (arrays handed out with reuse_buffers=True die with it)
-            self._lib.dw_pinned_free(self._pinned[0])
-            self._pinned = None
+        for blk in (getattr(self, "_pinned", None) or {}).values():   # (arrays handed out with reuse_buffers die with them)
+            self._lib.dw_pinned_free(blk[0])
+        self._pinned = {}
 
     def __del__(self):
         try:
@@ -281,12 +281,13 @@ class Engine:
                                              C.byref(alive)))
         return done_at, agents, alive.value
 
-    def snapshot_save(self):
-        """Device-side copy of the current state (planes, agents, reductions)."""
-        self._check(self._lib.dw_snapshot_save(self._h))
+    def snapshot_save(self, slot=0):
+        """Device-side copy of the current state (planes, the retained previous state, agents, reductions) into one of
+        the two slots."""
+        self._check(self._lib.dw_snapshot_save_slot(self._h, int(slot)))
 
-    def snapshot_restore(self):
-        self._check(self._lib.dw_snapshot_restore(self._h))
+    def snapshot_restore(self, slot=0):
+        self._check(self._lib.dw_snapshot_restore_slot(self._h, int(slot)))
 
     def run_episode(self, L_schedule, policy_mode, use_table=None, table=None, threshold_k=5, world_flags=True,
                     reuse_buffers=False):
@@ -333,7 +334,8 @@ class Engine:
         `params=None`: the parameter sets of the last call that passed them are still on the device and are used again
         (pass `n_members`).  `reuse_buffers=True`: the returned arrays are views of page-locked buffers owned by this
         engine (no staging copy on the way back) and are OVERWRITTEN by the next call with reuse_buffers=True - for
-        harnesses that consume a chunk's rewards before they run the next one."""
+        harnesses that consume a chunk's rewards before they run the next one.  `reuse_buffers=1` selects a SECOND such
+        buffer (True is buffer 0): a harness that runs chunk c + 1 while it still reads chunk c's rewards alternates."""
         Ls = np.ascontiguousarray(L_schedule, dtype=np.float64)
         K = Ls.shape[0]
         if params is None:
@@ -350,8 +352,8 @@ class Engine:
                 raise ValueError(f"member maps must have shape {(self.B,)}")
         split = self.N // 2 if split is None else int(split)
         n = K * self.B * self.N
-        if reuse_buffers and n:
-            buf = self._pinned_block(9 * n)
+        if reuse_buffers is not False and reuse_buffers is not None and n:
+            buf = self._pinned_block(9 * n, 0 if reuse_buffers is True else int(reuse_buffers))
             reward = np.frombuffer(buf, dtype=np.float64, count=n).reshape(K, self.B, self.N, 1)
             done = np.frombuffer(buf, dtype=np.uint8, count=n, offset=8 * n).reshape(K, self.B, self.N, 1)
         else:
@@ -361,18 +363,20 @@ class Engine:
                                            _ffi.ptr_i(mb), split, float(L_init), _ffi.ptr_d(reward), _ffi.ptr_u8(done)))
         return reward, done.view(np.bool_)
 
-    def _pinned_block(self, nbytes):
-        """A page-locked host buffer of at least nbytes owned by this engine (grown geometrically, freed by close())."""
-        have = getattr(self, "_pinned", None)
+    def _pinned_block(self, nbytes, index=0):
+        """Page-locked host buffer number `index` of at least nbytes owned by this engine (grown geometrically, freed by
+        close())."""
+        blocks = self.__dict__.setdefault("_pinned", {})
+        have = blocks.get(index)
         if have is None or have[1] < nbytes:
             if have is not None:
                 self._lib.dw_pinned_free(have[0])
-                self._pinned = None
+                del blocks[index]
             size = max(int(nbytes), 2 * (have[1] if have else 0), 1 << 20)
             ptr = C.c_void_p()
             self._check(self._lib.dw_pinned_alloc(size, C.byref(ptr)))
-            self._pinned = (ptr, size, (C.c_ubyte * size).from_address(ptr.value))
-        return self._pinned[2]
+            blocks[index] = (ptr, size, (C.c_ubyte * size).from_address(ptr.value))
+        return blocks[index][2]
 
     # -- plumbing -----------------------------------------------------------------------------
     def set_stream(self, hip_stream_ptr: int):

@@ -193,29 +193,62 @@ def _mlp_chunks(env, params, member_a, member_b, half, max_steps, chunk, after_c
     done flags of the chunk: it accounts for the steps up to and including the one that ends the episode, with
     every float64 sum accumulated in step order.  When the episode ends inside a chunk, the chunk is replayed
     from a device-side snapshot for exactly the executed steps, so the environment is left where the
-    reference's loop leaves it."""
+    reference's loop leaves it.
+
+    The device runs chunk c + 1 while this thread accounts for chunk c (a worker thread around the blocking C calls,
+    which release the GIL): the bookkeeping - NumPy reductions in the reference's order over 4 MB of rewards per chunk
+    for a population of 64 x 32 worlds - costs more than the chunk's kernel.  Chunk c + 1 does not depend on it except
+    for "has the episode ended": its rewards go to the engine's second page-locked buffer, the state at its start to
+    snapshot slot (c + 1) % 2, and when chunk c turns out to end the episode the speculative chunk is undone from the
+    snapshots (slot c % 2 + a replay of the executed steps, or slot (c + 1) % 2 as it is when chunk c ran to its end)."""
     eng = env._engine
-    first, finished = True, False
     n_members = np.asarray(params).reshape(-1, 1808).shape[0]
-    while not finished and env.step_count < max_steps:
-        K = 1 if first else min(int(chunk), max_steps - env.step_count)    # step 1 starts from the un-quantised state
-        Ls = _luminosity_schedule(env, K)
-        env._sync_to_device()
-        if K > 1:
-            eng.snapshot_save()
+    if env.step_count >= max_steps:
+        return
+    env._sync_to_device()
+
+    def on_device(c, Ls, L_init, first):
+        if not first:                                    # (the first step starts from the un-quantised state: nothing to save,
+            eng.snapshot_save(c & 1)                     # and it is never undone - it always runs to its end)
         # the parameter sets go up with the first chunk and stay on the device; rewards / done flags come back in the
-        # engine's page-locked buffers (consumed by after_chunk before the next chunk overwrites them)
-        rewards, dones = eng.run_episode_mlp(Ls, params if first else None, member_a, member_b, half, env._L_pass,
-                                             reuse_buffers=True, n_members=n_members)
-        # (the device already returns reward * (reward > 0), ref step :490: agent states are clipped to [0, 1], so the
-        # product is the state itself - a second pass over the (K,B,N,1) array would change no bit of it)
-        executed, finished = after_chunk(rewards, dones)
-        if executed < K:
-            eng.snapshot_restore()
-            eng.run_episode_mlp(Ls[:executed], None, member_a, member_b, half, env._L_pass, reuse_buffers=True,
-                                n_members=n_members)
-        _advance_host_scalars(env, executed)
-        first = False
+        # engine's page-locked buffers (consumed by after_chunk before the chunk after the next overwrites them)
+        return eng.run_episode_mlp(Ls, params if first else None, member_a, member_b, half, L_init,
+                                   reuse_buffers=c & 1, n_members=n_members)
+
+    pool = ThreadPoolExecutor(max_workers=1)
+    try:
+        c, K = 0, 1                                      # step 1 starts from the un-quantised state: a chunk of its own
+        Ls = _luminosity_schedule(env, K)
+        L_init = env._L_pass
+        pending = pool.submit(on_device, c, Ls, L_init, True)
+        while True:
+            rewards, dones = pending.result()
+            ahead = None
+            left = max_steps - (env.step_count + K)
+            if left > 0:                                 # chunk c + 1, before chunk c is accounted for
+                K_n = min(int(chunk), left)
+                sched = _luminosity_schedule(env, K + K_n)
+                Ls_n, L_init_n = sched[K:], sched[K - 1]
+                ahead = pool.submit(on_device, c + 1, Ls_n, L_init_n, False)
+            # (the device already returns reward * (reward > 0), ref step :490: agent states are clipped to [0, 1], so the
+            # product is the state itself - a second pass over the (K,B,N,1) array would change no bit of it)
+            executed, finished = after_chunk(rewards, dones)
+            if executed < K or finished:
+                if ahead is not None:
+                    ahead.result()                       # the speculative chunk has to leave the device first
+                if executed < K:                         # ended inside chunk c: its start + exactly the executed steps
+                    eng.snapshot_restore(c & 1)
+                    eng.run_episode_mlp(Ls[:executed], None, member_a, member_b, half, L_init, reuse_buffers=c & 1,
+                                        n_members=n_members)
+                elif ahead is not None:                  # ended with chunk c's last step: the state chunk c + 1 started from
+                    eng.snapshot_restore((c + 1) & 1)
+                ahead = None
+            _advance_host_scalars(env, executed)
+            if ahead is None:
+                return                                   # the episode ended, or max_steps is reached
+            pending, c, K, Ls, L_init = ahead, c + 1, K_n, Ls_n, L_init_n
+    finally:
+        pool.shutdown(wait=True)
 
 
 def _fitness_chunk(acc, rewards, dones, half):
