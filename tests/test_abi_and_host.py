@@ -384,3 +384,51 @@ def test_ft_convolve_refuses_what_it_does_not_implement_before_touching_a_device
     with pytest.raises(ValueError):
         ft_convolve(np.zeros((2, 1, 2, 8)), k)
     assert make_neighborhood(1, "von_neumann").tolist() == [[0, 1, 0], [1, 1, 1], [0, 1, 0]]
+
+
+def test_host_helper_draws_numpys_legacy_stream_bit_for_bit():
+    """include/daisyworld_host.h: dw_mt19937_random_sample = np.random.rand on the global legacy generator - the same
+    doubles AND the same state afterwards (later rand / randn / randint calls continue identically), from any position in
+    the 624-word state, with a cached Gaussian pending, across block boundaries; RLDaisyWorld._legacy_rand falls back to
+    NumPy for small draws and gives the same numbers either way."""
+    import re
+    import subprocess
+    from therldaisyworld_amd import _ffi, build
+    from therldaisyworld_amd.daisy_world_rl import RLDaisyWorld
+    build.build_host_library()
+    host = _ffi.load_host()
+    assert host is not None and host.dw_host_abi_version() == _ffi.DW_HOST_ABI_VERSION
+    # every function the header declares is exported
+    header = open(os.path.join(ROOT, "include", "daisyworld_host.h")).read()
+    declared = set(re.findall(r"^int\s+(dw_\w+)\s*\(", header, flags=re.M))
+    exported = subprocess.run(["nm", "-D", "--defined-only", build.HOST_LIB], capture_output=True, text=True).stdout
+    assert declared == {"dw_mt19937_random_sample", "dw_host_abi_version"}
+    for name in declared:
+        assert re.search(rf"\bT {name}\b", exported), name
+    rng = np.random.RandomState(5)
+    saved = np.random.get_state()
+    try:
+        for trial in range(120):
+            np.random.seed(int(rng.randint(2 ** 31)))
+            pre = int(rng.randint(0, 1500))
+            if pre:
+                np.random.rand(pre)
+            if rng.rand() < 0.3:
+                np.random.randn(1)                           # leaves a cached Gaussian in the state
+            shape = [(4096,), (4097,), (5000,), (8, 2, 16, 16), (3, 2, 40, 41), (100003,), (623 * 8,), (624 * 8 + 1,)][trial % 8]
+            st = np.random.get_state()
+            a, a2, g, r = np.random.rand(*shape), np.random.rand(7), np.random.randn(3), np.random.randint(9, size=5)
+            np.random.set_state(st)
+            b = RLDaisyWorld._legacy_rand(*shape)
+            b2, g2, r2 = np.random.rand(7), np.random.randn(3), np.random.randint(9, size=5)
+            assert b.shape == a.shape and np.array_equal(a, b), (trial, shape)
+            assert np.array_equal(a2, b2) and np.array_equal(g, g2) and np.array_equal(r, r2), (trial, shape)
+        # bad arguments are refused without touching anything
+        key = np.zeros(624, dtype=np.uint32)
+        pos = C.c_int32(700)
+        out = np.zeros(4)
+        assert host.dw_mt19937_random_sample(key.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(pos),
+                                             out.ctypes.data_as(C.POINTER(C.c_double)), 4) == -1
+        assert pos.value == 700 and not out.any()
+    finally:
+        np.random.set_state(saved)

@@ -137,6 +137,32 @@ def load(path=None):
     return _libs[path]
 
 
+HOST_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libdaisyworld_host.so")
+DW_HOST_ABI_VERSION = 1
+_host = []
+
+
+def load_host():
+    """The optional host helper (include/daisyworld_host.h: NumPy's legacy random stream in bulk), or None when it has not
+    been built - its callers then use NumPy itself, with identical results."""
+    if not _host:
+        lib = None
+        if os.path.exists(HOST_LIB_PATH):
+            try:
+                lib = C.CDLL(HOST_LIB_PATH)
+                lib.dw_host_abi_version.restype = C.c_int
+                lib.dw_host_abi_version.argtypes = []
+                lib.dw_mt19937_random_sample.restype = C.c_int
+                lib.dw_mt19937_random_sample.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_int32), C.POINTER(C.c_double),
+                                                         C.c_size_t]
+                if lib.dw_host_abi_version() != DW_HOST_ABI_VERSION:
+                    lib = None
+            except (OSError, AttributeError):
+                lib = None
+        _host.append(lib)
+    return _host[0]
+
+
 def check(rc, lib=None):
     """Raise on a non-zero return code, with the message of the library that produced it."""
     if rc != DW_OK:

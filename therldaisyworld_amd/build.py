@@ -85,6 +85,46 @@ def build_variant(name: str, defines, force: bool = False, verbose: bool = False
     return out
 
 
+# ---- the optional host helper (gcc; NumPy's legacy random stream in bulk, include/daisyworld_host.h) ---------------
+HOST_LIB = os.path.join(HERE, "libdaisyworld_host.so")
+HOST_SOURCE = os.path.join(CSRC, "dw_hostrng.c")
+HOST_HEADER = os.path.join(HERE, "..", "include", "daisyworld_host.h")
+HOST_FLAGS = ["-O3", "-fPIC", "-shared", "-Wall", "-Wextra"]
+_HOST_MARK = b"DW_HOST_BUILD_ID="
+
+
+def host_source_id() -> str:
+    h = hashlib.sha256()
+    for path in (HOST_SOURCE, HOST_HEADER):
+        with open(path, "rb") as f:
+            h.update(f.read())
+    h.update(" ".join(HOST_FLAGS).encode())
+    return h.hexdigest()[:16]
+
+
+def host_library_id(path: str = HOST_LIB) -> str | None:
+    try:
+        with open(path, "rb") as f:
+            blob = f.read()
+    except OSError:
+        return None
+    i = blob.find(_HOST_MARK)
+    return None if i < 0 else blob[i + len(_HOST_MARK): i + len(_HOST_MARK) + 16].decode("ascii", "replace")
+
+
+def build_host_library(force: bool = False, verbose: bool = False) -> str:
+    """Compile libdaisyworld_host.so with gcc unless the one in the tree was built from exactly these sources."""
+    if force or host_library_id() != host_source_id():
+        gcc = shutil.which("gcc") or shutil.which("cc")
+        if not gcc:
+            raise RuntimeError("gcc not found: cannot build " + os.path.basename(HOST_LIB))
+        cmd = [gcc, *HOST_FLAGS, f'-DDW_HOST_BUILD_ID="{host_source_id()}"', "-o", HOST_LIB, HOST_SOURCE]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd, cwd=CSRC)
+    return HOST_LIB
+
+
 def build_tuning_library(verbose: bool = False) -> str:
     """-DDW_TUNING build with ablation hooks (tools/kbench.py only)."""
     return build_variant("tuning", ["DW_TUNING"], verbose=verbose)
@@ -96,3 +136,4 @@ if __name__ == "__main__":
         print(build_variant(sys.argv[1], sys.argv[2:], force=True, verbose=True))
     else:
         print(build_library(force=True, verbose=True))
+        print(build_host_library(force=True, verbose=True))
