@@ -24,6 +24,17 @@ extern "C" {
  * argument (null pointer, pos outside 0..624). */
 int dw_mt19937_random_sample(uint32_t* key, int32_t* pos, double* out, size_t n);
 
+/* The epsilon branch of the reference's Greedy policy (daisy/agents/greedy.py:32: `np.random.randint(9, size=(B, N, 1, 1))`,
+ * once per step for the whole batch): n integers of np.random.randint(low, low + rng + 1) from the same legacy stream, bit for
+ * bit, for 0 < rng < 2^32 - 1 (NumPy's masked-rejection path on 32-bit words).  Same state convention as above. */
+int dw_mt19937_randint(uint32_t* key, int32_t* pos, int64_t low, uint64_t rng, int64_t* out, size_t n);
+
+/* The same policy's draws for a CHUNK of K steps in the reference's order (greedy.py:23-32: per call one np.random.rand() coin,
+ * the deterministic branch iff coin > epsilon, else randint(9, size=(B, N, 1, 1))): use_table[t] in {0, 1}, table[t][per_step]
+ * (int8, rows of greedy steps untouched) - what dw_run_episode takes (daisyworld_hip.h), with one state exchange per chunk. */
+int dw_mt19937_greedy_draws(uint32_t* key, int32_t* pos, double epsilon, int32_t K, size_t per_step, uint8_t* use_table,
+                            int8_t* table);
+
 int dw_host_abi_version(void);
 
 #ifdef __cplusplus

@@ -155,6 +155,12 @@ def load_host():
                 lib.dw_mt19937_random_sample.restype = C.c_int
                 lib.dw_mt19937_random_sample.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_int32), C.POINTER(C.c_double),
                                                          C.c_size_t]
+                lib.dw_mt19937_randint.restype = C.c_int
+                lib.dw_mt19937_randint.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_int32), C.c_int64, C.c_uint64,
+                                                   C.POINTER(C.c_int64), C.c_size_t]
+                lib.dw_mt19937_greedy_draws.restype = C.c_int
+                lib.dw_mt19937_greedy_draws.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_int32), C.c_double, C.c_int32,
+                                                        C.c_size_t, C.POINTER(C.c_uint8), C.POINTER(C.c_int8)]
                 if lib.dw_host_abi_version() != DW_HOST_ABI_VERSION:
                     lib = None
             except (OSError, AttributeError):

@@ -130,4 +130,69 @@ int dw_mt19937_random_sample(uint32_t* key, int32_t* pos, double* out, size_t n)
     return 0;
 }
 
+/* np.random.randint(low, low + rng + 1, size=n) of the legacy generator for a range that fits 32 bits (the epsilon branch of
+ * the reference's Greedy policy, daisy/agents/greedy.py:32: randint(9, size=(B, N, 1, 1)) once per step): NumPy's legacy
+ * path draws 32-bit words and keeps `word & mask` (mask = the smallest 2^k - 1 >= rng) whenever it is <= rng - masked
+ * rejection, one word per attempt (numpy/random/src/distributions/distributions.c, buffered_bounded_masked_uint32 as called by
+ * random_bounded_uint64_fill with use_masked: restated).  Returns 0, -1 for a bad argument (rng == 0 or >= 2^32 - 1 are
+ * other paths of NumPy's and are refused). */
+int dw_mt19937_randint(uint32_t* key, int32_t* pos, int64_t low, uint64_t rng, int64_t* out, size_t n) {
+    if (!key || !pos || (!out && n) || *pos < 0 || *pos > MT_N || rng == 0 || rng >= 0xFFFFFFFFull) return -1;
+    uint32_t mask = (uint32_t)rng;
+    mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+    const uint32_t r = (uint32_t)rng;
+    uint32_t block[MT_N];
+    int p = *pos;
+    size_t done = 0;
+    while (done < n && p < MT_N) {                          /* what is left of the current state */
+        const uint32_t v = temper(key[p++]) & mask;
+        if (v <= r) out[done++] = low + (int64_t)v;
+    }
+    while (done < n) {
+        mt_block(key, block);
+        p = 0;
+        while (done < n && p < MT_N) {
+            const uint32_t v = block[p++] & mask;
+            out[done] = low + (int64_t)v;
+            done += v <= r;
+        }
+    }
+    *pos = p;
+    return 0;
+}
+
+/* The draws of K calls of the reference's Greedy policy (daisy/agents/greedy.py:23-32) for a batch of `per_step` agents, in its
+ * order: per call ONE np.random.rand() - the call takes its deterministic branch iff that coin > epsilon - and on the other
+ * branch np.random.randint(9, size=(B, N, 1, 1)).  use_table[t] = 1 and table[t * per_step ..] = the actions of step t when step t
+ * draws its actions, use_table[t] = 0 (row untouched) when it is greedy.  One state exchange per chunk of steps instead of
+ * two NumPy calls per step. */
+int dw_mt19937_greedy_draws(uint32_t* key, int32_t* pos, double epsilon, int32_t K, size_t per_step, uint8_t* use_table,
+                            int8_t* table) {
+    if (!key || !pos || *pos < 0 || *pos > MT_N || K < 0 || (K && !use_table) || (K && per_step && !table)) return -1;
+    uint32_t block[MT_N];
+    int p = *pos;
+    for (int k = p; k < MT_N; ++k) block[k] = temper(key[k]);            /* what is left of the current state */
+    for (int32_t t = 0; t < K; ++t) {
+        if (p == MT_N) { mt_block(key, block); p = 0; }
+        const uint32_t a = block[p++] >> 5;
+        if (p == MT_N) { mt_block(key, block); p = 0; }
+        const uint32_t b = block[p++] >> 6;
+        const double coin = ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
+        if (coin > epsilon) { use_table[t] = 0; continue; }
+        use_table[t] = 1;
+        int8_t* row = table + (size_t)t * per_step;
+        size_t done = 0;
+        while (done < per_step) {
+            if (p == MT_N) { mt_block(key, block); p = 0; }
+            while (done < per_step && p < MT_N) {                         /* (branch-free: the acceptance is a coin flip) */
+                const uint32_t v = block[p++] & 15u;                      /* randint(9): range 8, mask 15 */
+                row[done] = (int8_t)v;
+                done += v <= 8u;
+            }
+        }
+    }
+    *pos = p;
+    return 0;
+}
+
 int dw_host_abi_version(void) { return DW_HOST_ABI_VERSION; }
