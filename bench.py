@@ -255,7 +255,7 @@ def main():
     dist = ensemble.init_process_group(args.backend, device=local_rank) if (world > 1 or force_group) else None
 
     import therldaisyworld_amd as amd
-    from therldaisyworld_amd import _ffi
+    from therldaisyworld_amd import _ffi, telemetry
 
     min_L, max_L, dL = 0.75, 1.5, 0.75 / 512
 
@@ -282,47 +282,6 @@ def main():
                 if e.code != _ffi.DW_ENOMEM or B == 1:
                     raise
                 B //= 2
-
-    def board_power_while(work, settle_s=0.45, samples=3):
-        """Board power and engine clock WHILE `work()` (a blocking library call: ctypes releases the GIL) runs on a helper
-        thread - rocm-smi read beside it, after `settle_s` (the power manager needs a few hundred ms to reach its steady
-        state).  An untimed extra pass after the timed region; every failure (no rocm-smi, unexpected output) gives None."""
-        import re
-        import shutil
-        import subprocess
-        import threading
-        smi = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
-        err = []
-
-        def guarded():
-            try:
-                work()
-            except Exception as e:                      # (reported in the object instead of a traceback on a helper thread)
-                err.append(f"work: {type(e).__name__}: {e}")
-
-        th = threading.Thread(target=guarded)
-        got = []
-        t_start = time.perf_counter()
-        th.start()
-        try:
-            time.sleep(settle_s)
-            while th.is_alive() and len(got) < samples:
-                txt = subprocess.run([smi, "-d", str(local_rank), "--showpower", "--showclocks", "--showmaxpower"],
-                                     capture_output=True, text=True, timeout=20).stdout
-                w = re.search(r"Current Socket Graphics Package Power \(W\): *([0-9.]+)", txt) or \
-                    re.search(r"Average Graphics Package Power \(W\): *([0-9.]+)", txt)
-                c = re.search(r"sclk clock level: *\S+ *\((\d+)Mhz\)", txt)
-                mx = re.search(r"Max Graphics Package Power \(W\): *([0-9.]+)", txt)
-                if w and c and th.is_alive():           # (a sample that ended after the work did is not one of it)
-                    got.append((float(w.group(1)), int(c.group(1)), float(mx.group(1)) if mx else None))
-        except Exception as e:
-            err.append(f"rocm-smi: {type(e).__name__}: {e}")
-        th.join()
-        if not got:
-            return {"board_w": None, "error": "; ".join(err) or f"no sample while the work ran ({time.perf_counter() - t_start:.2f} s)"}
-        return {"board_w": max(g[0] for g in got), "limit_w": got[0][2], "sclk_mhz": sorted(g[1] for g in got)[len(got) // 2],
-                "samples": [[g[0], g[1]] for g in got], "busy_s": round(time.perf_counter() - t_start, 2),
-                "source": "rocm-smi --showpower --showclocks beside an untimed extra pass of the same launches"}
 
     def measure(workload, precision, steps, warmup, preheat_s, worlds=0, power=False):
         """One timed run of `steps` steps of `workload` in the given arithmetic mode."""
@@ -416,7 +375,8 @@ def main():
             # ~2 s more of the same launches at the luminosity reached, untimed (everything the line reports was read
             # above), with the board's power and engine clock read beside them
             extra = int(min(max(2.0 / max(elapsed / steps, 1e-6), 8), 20000))
-            pw = board_power_while(lambda: (run(extra + (extra & 1), L, 0.0), eng.sync()))   # (dw_step_n only enqueues)
+            pw = telemetry.board_power_while(lambda: (run(extra + (extra & 1), L, 0.0), eng.sync()),   # (dw_step_n only enqueues)
+                                              device=local_rank)
         res = {"workload": workload, "power": pw, "desc": desc, "precision": precision, "B": B, "G": G, "N": N, "cells": cells,
                "value": cells * steps * n_gpus / elapsed, "ms_per_step": elapsed / steps * 1e3,
                "rank_value": cells * steps / own_elapsed,

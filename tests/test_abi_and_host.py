@@ -464,3 +464,35 @@ def test_host_helper_draws_numpys_legacy_stream_bit_for_bit():
         assert pos.value == 700 and not out.any()
     finally:
         np.random.set_state(saved)
+
+
+def test_board_power_sampler_parses_rocm_smi_and_reports_failures(tmp_path, monkeypatch):
+    """therldaisyworld_amd.telemetry.board_power_while (bench.py's "power" object) against a stand-in rocm-smi that prints the
+    tool's own format: maximum of the power samples, median clock, the limit; a missing tool, unparsable output, work that
+    raises or ends before the first sample all come back as {"board_w": None, "error": ...}."""
+    import stat
+    import time
+    from therldaisyworld_amd import telemetry
+    fake = tmp_path / "rocm-smi"
+    fake.write_text("#!/bin/sh\ncat <<'X'\n"
+                    "============================ ROCm System Management Interface ============================\n"
+                    "GPU[0]\t\t: fclk clock level: 0: (1250Mhz)\n"
+                    "GPU[0]\t\t: sclk clock level: 1: (2140Mhz)\n"
+                    "GPU[0]\t\t: Max Graphics Package Power (W): 1400.0\n"
+                    "GPU[0]\t\t: Current Socket Graphics Package Power (W): 1389.0\nX\n")
+    fake.chmod(fake.stat().st_mode | stat.S_IEXEC)
+    monkeypatch.setenv("PATH", str(tmp_path) + os.pathsep + os.environ["PATH"])
+    pw = telemetry.board_power_while(lambda: time.sleep(0.6), settle_s=0.05, samples=2)
+    assert pw["board_w"] == 1389.0 and pw["limit_w"] == 1400.0 and pw["sclk_mhz"] == 2140 and len(pw["samples"]) == 2
+    # the work is over before the first sample
+    pw = telemetry.board_power_while(lambda: None, settle_s=0.05)
+    assert pw["board_w"] is None and "no sample" in pw["error"]
+    # the work raises: reported, not thrown
+    def boom():
+        raise RuntimeError("kernel fault")
+    pw = telemetry.board_power_while(boom, settle_s=0.05)
+    assert pw["board_w"] is None and "kernel fault" in pw["error"]
+    # unparsable output
+    fake.write_text("#!/bin/sh\necho nothing useful\n")
+    pw = telemetry.board_power_while(lambda: time.sleep(0.3), settle_s=0.05)
+    assert pw["board_w"] is None
