@@ -257,6 +257,14 @@ def main():
     import therldaisyworld_amd as amd
     from therldaisyworld_amd import _ffi, telemetry
 
+    # torch's import leaves ~10^6 objects tracked by the cyclic collector: a full collection costs 40-50 ms and is triggered by
+    # allocation COUNTS, i.e. it lands in whichever timed region reaches the count (seen as +41 ms in ONE policy of
+    # tools/lifespan_sweep.py, a different one when the run was instrumented).  Collect now, then take everything alive out
+    # of the collector's reach: later collections only look at what the measurement itself allocates.
+    import gc
+    gc.collect()
+    gc.freeze()
+
     min_L, max_L, dL = 0.75, 1.5, 0.75 / 512
 
     def make_engine(B, G, N, precision):

@@ -102,6 +102,12 @@ def main():
     import therldaisyworld_amd as amd
     from therldaisyworld_amd.harness import simulate_lifespan
 
+    # (torch's import leaves ~10^6 collector-tracked objects: a full collection is 40-50 ms and would land inside one
+    # policy's timed episode - whichever reaches the allocation count; see bench.py)
+    import gc
+    gc.collect()
+    gc.freeze()
+
     policies = [("greedy", lambda: amd.Greedy(epsilon=0.0)),
                 ("antigreedy", lambda: amd.Greedy(epsilon=0.0, greedy=False)),
                 ("random", lambda: amd.Greedy(epsilon=1.0)),
