@@ -2,7 +2,7 @@
 """Where a dw_run_episode call's wall time goes on the small-world episode path (1000 worlds of 8x8, 4 greedy agents, as
 bench.py's c4_dim8): per call of K steps - the Python wrapper, the C call, the kernel (HIP events on the library's stream).
 
-usage: episode_overhead.py [precision=exact] [calls=200] [K,K,...=16,64,256]"""
+usage: episode_overhead.py [precision=exact] [calls=200] [K,K,...=16,64,256] [grid=8] [worlds=1000]"""
 import os
 import sys
 import time
@@ -15,7 +15,9 @@ from therldaisyworld_amd import _ffi  # noqa: E402
 precision = sys.argv[1] if len(sys.argv) > 1 else "exact"
 calls = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 Ks = [int(k) for k in sys.argv[3].split(",")] if len(sys.argv) > 3 else [16, 64, 256]
-B, G, N = 1000, 8, 4
+G = int(sys.argv[4]) if len(sys.argv) > 4 else 8
+B = int(sys.argv[5]) if len(sys.argv) > 5 else 1000
+N = 4
 p = amd.default_params(B, G, G, N)
 p.precision = _ffi.PRECISION[precision]
 eng = amd.Engine(p)
@@ -57,7 +59,7 @@ for K in Ks:
         eng.timer_start()
         eng.run_episode(Ls, _ffi.POLICY_ARGMAX, reuse_buffers=True)
         ev += eng.timer_stop()
-    print(f"{precision} K={K}: wall {wall / calls * 1e6:.1f} us per call = {wall / calls / K * 1e6:.3f} us/step; C call "
+    print(f"{precision} {B} x {G}x{G} K={K}: wall {wall / calls * 1e6:.1f} us per call = {wall / calls / K * 1e6:.3f} us/step; C call "
           f"{c_time[0] / calls * 1e6:.1f} us; stream time (copy up, kernel, copy down) {ev / 20 * 1e3:.1f} us; "
           f"python wrapper {(wall - c_time[0]) / calls * 1e6:.1f} us", flush=True)
 eng.close()
