@@ -146,6 +146,16 @@ class RLDaisyWorld:
     # ------------------------------------------------------------------------------------------
     # engine management
     # ------------------------------------------------------------------------------------------
+    _PARAM_FLOATS = ("p", "g", "S", "sigma", "gamma", "q", "q2", "dt", "albedo_bare", "albedo_light", "albedo_dark",
+                     "temp_optimal", "agent_gamma", "food_chain_penalty", "initial_al", "initial_ad", "light_proportion",
+                     "dark_proportion")
+
+    def _param_key(self):
+        """Everything _params() reads, as one tuple: the reference reads its attributes live on every call, so the class
+        looks at them on every call too - but builds and pushes a dw_params only when one of them changed."""
+        return (self.batch_size, self.dim, self.n_agents, self.device, self.precision, self.collision_mode, self.world_offset,
+                self.neighborhood.tobytes(), *[getattr(self, name) for name in self._PARAM_FLOATS])
+
     def _params(self):
         p = default_params(int(self.batch_size), int(self.dim), int(self.dim), int(self.n_agents))
         p.device = int(self.device)
@@ -162,8 +172,12 @@ class RLDaisyWorld:
     def _ensure_engine(self):
         """(Re)create the device handle when the caller changed batch_size / dim / n_agents, and push
         the current constants (the reference reads its attributes live on every call)."""
+        key = self._param_key()
+        if self._engine is not None and key == getattr(self, "_pushed_key", None):
+            return self._engine                              # nothing changed since the last push
         shape = (int(self.batch_size), int(self.dim), int(self.n_agents), int(self.device))
         p = self._params()
+        self._pushed_key = key
         if self._engine is None or shape != self._shape:
             if self._engine is not None:
                 self._engine.close()
