@@ -132,3 +132,28 @@ def test_first_step_stream_kernels_are_packed_and_spill_free(asm):
         npk = sum(1 for ln in loop if ln.startswith("\tv_pk_"))
         ntr = sum(1 for ln in loop if re.match(r"\tv_(sqrt|rcp)_f32", ln))
         assert npk >= 40 and ntr == (32 if bounded else 24), (name, npk, ntr)   # 4 cells x (6 + the bound's two roots)
+
+
+def test_episode_wave_step_loop_has_no_scratch_and_few_branches(asm):
+    """episode_wave (one wave per world: every instruction of the step costs its lone wave ~5-7 cycles): no scratch access in
+    either instantiation (a by-reference struct of the reachable covers once lived there: 56 bytes stored and a dependent
+    load per step), the first-to-graze loop is the mask form (one v_readlane + one v_cmp per agent: at most 12 instructions
+    per iteration), and the float32 kernel keeps 4 waves/SIMD."""
+    ks = {n: v for n, v in _kernels(asm).items() if re.search(r"episode_waveILb[01]EE", n)}
+    assert len(ks) == 2
+    for name, (info, body) in ks.items():
+        assert not re.search(r"\tscratch_", body), name
+        lines = body.split("\n")
+        labels = {m.group(1): i for i, ln in enumerate(lines) for m in [re.match(r"(\.LBB\S+):", ln)] if m}
+        # innermost loops that read a lane: the conflict loop
+        loops = []
+        for i, ln in enumerate(lines):
+            m = re.match(r"\ts_cbranch\S* (\.LBB\S+)", ln)
+            if m and m.group(1) in labels and labels[m.group(1)] < i:
+                seg = [x for x in lines[labels[m.group(1)]:i + 1] if x.startswith("\t") and not x.startswith("\t;")]
+                if any(x.startswith("\tv_readlane_b32") for x in seg) and len(seg) < 40:
+                    loops.append(seg)
+        assert loops, name
+        assert min(len(seg) for seg in loops) <= 12, (name, [len(s) for s in loops])
+        if "ILb0EE" in name:
+            assert info["Occupancy"] >= 4, (name, info["NumVgprs"])
