@@ -916,10 +916,12 @@ def test_episode_table_codes_for_greedy_choices(amd):
             assert np.array_equal(x, y)
 
 
-@pytest.mark.parametrize("B,H,W", [(9, 32, 32), (3, 72, 72), (2, 40, 256), (2, 66, 520)])
+@pytest.mark.parametrize("B,H,W", [(9, 32, 32), (3, 72, 72), (2, 40, 256), (2, 66, 520),
+                                   (5, 17, 17), (6, 20, 24), (4, 31, 33), (3, 16, 64), (3, 64, 16), (130, 24, 24), (7, 3, 300)])
 def test_run_episode_matches_stepwise_engine(amd, B, H, W):
     """dw_run_episode == K x (policy + dw_step): planes, agents, flags, reductions, previous state —
-    LDS-resident kernel (32x32) and the back-to-back-launch path of larger worlds (tiled / streaming)."""
+    LDS-resident kernels (episode_small: 32x32, 72x72, odd and non-square grids with 256 < H*W <= 1024, more worlds than one
+    round of workgroups, a 3-row world) and the back-to-back-launch path of larger worlds (tiled / streaming)."""
     from therldaisyworld_amd import _ffi
     N, K = 5, 11
     outs = []

@@ -21,7 +21,7 @@ from oracle import daisy_oracle as O  # noqa: E402
 
 def _run_case(seed, log):
     rng = np.random.RandomState(seed)
-    dim = int(rng.choice([8, 12, 16, 32, 64, 72, 128, 256]))
+    dim = int(rng.choice([8, 12, 16, 17, 20, 24, 31, 32, 64, 72, 128, 256]))
     N = int(rng.randint(1, 5))
     B = int(rng.choice([1, 3, 7])) if dim <= 72 else int(rng.choice([1, 2]))
     eps = float(rng.choice([0.0, 0.5, 1.0]))
