@@ -28,6 +28,18 @@ from .agents.greedy import Greedy
 LIFESPAN_THRESHOLD_K = 5          # grid_done = max cover <= 0.005 (notebook cell 2:48)
 
 
+def _count_true(flags):
+    """Number of set flags along axis 0 of a (K, ...) array of 0 / 1 bytes (bool or uint8), as intp - `flags.sum(axis=0)`.
+    Eight flags at a time: the bytes are summed as uint64 words (no byte can carry for K <= 255), 8x less work than
+    NumPy's bool -> int64 reduction (137 -> 17 us for 32 x 1000 x 4 flags: a third of a chunk's host time on 8x8 worlds)."""
+    K, rest = flags.shape[0], flags.shape[1:]
+    n = int(np.prod(rest, dtype=np.int64))
+    if 0 < K <= 255 and n and n % 8 == 0 and flags.flags.c_contiguous and flags.dtype.itemsize == 1:
+        words = flags.view(np.uint8).reshape(K, n).view(np.uint64).sum(axis=0)
+        return words.view(np.uint8).reshape(rest).astype(np.intp)
+    return np.count_nonzero(flags, axis=0)
+
+
 def _grid_done(env):
     """ref notebook cell 2:48: `env.grid[:, 1:3].max(axis=(1, 2, 3)) <= 0.005` per world.  On the drop-in
     environment the per-world maximum is a by-product of the step kernel (per-mille integer, `dw_reduce`):
@@ -131,7 +143,9 @@ def simulate_lifespan(env, agent, chunk=32, use_device_loop=True, obs=None, fina
         rng_before = np.random.get_state() if agent is not None else None
         use_table = np.zeros(K, dtype=np.uint8)
         table = np.zeros((K, B, N), dtype=np.int8)
-        if agent is not None and not draws_in_c(rng_before, K, use_table, table):
+        # (a policy that never takes its random branch draws one coin per step: K scalar draws are cheaper than the state
+        # exchange with the helper)
+        if agent is not None and not (agent.epsilon > 0.0 and draws_in_c(rng_before, K, use_table, table)):
             for t in range(K):
                 if not agent.draw_branch():
                     use_table[t] = 1
@@ -143,7 +157,7 @@ def simulate_lifespan(env, agent, chunk=32, use_device_loop=True, obs=None, fina
         if rng_before is None:
             return
         scratch_ut, scratch_tb = np.zeros(max(steps, 1), dtype=np.uint8), np.zeros((max(steps, 1), B, N), dtype=np.int8)
-        if draws_in_c(rng_before, steps, scratch_ut, scratch_tb):
+        if agent.epsilon > 0.0 and draws_in_c(rng_before, steps, scratch_ut, scratch_tb):
             return
         np.random.set_state(rng_before)
         for _ in range(steps):
@@ -180,8 +194,8 @@ def simulate_lifespan(env, agent, chunk=32, use_device_loop=True, obs=None, fina
             all_dead = ~alive_k.any(axis=1)
             ended = bool(all_dead.any())                       # also when the last world died on the chunk's last step
             executed = int(np.argmax(all_dead)) + 1 if ended else K
-            done_at += alive_k[:executed].sum(axis=0)
-            agents_done_at += ok_k[:executed].sum(axis=0)[..., None]
+            done_at += _count_true(alive_k[:executed])
+            agents_done_at += _count_true(ok_k[:executed])[..., None]
             if not final_state:
                 executed = K                                   # the environment stays where the chunk ended
             elif executed < K:
@@ -305,7 +319,7 @@ def _population_chunk(acc, rewards, dones, half, worlds_per_member):
     none_left = np.nonzero(~(run_t & ~all_done).any(axis=1))[0]
     executed = int(none_left[0]) + 1 if none_left.size else K
     if run_t[:executed].all():                                                     # the usual chunk: every member still runs
-        alive = executed - np.count_nonzero(dones[:executed], axis=0)              # = sum(1 - done): integers, any order
+        alive = executed - _count_true(dones[:executed])                           # = sum(1 - done): integers, any order
     else:
         live = np.repeat(run_t[:executed], worlds_per_member, axis=1)[:, :, None, None]
         alive = np.count_nonzero(live & ~dones[:executed], axis=0)                 # = sum(live * (1 - done))
