@@ -496,3 +496,19 @@ def test_board_power_sampler_parses_rocm_smi_and_reports_failures(tmp_path, monk
     fake.write_text("#!/bin/sh\necho nothing useful\n")
     pw = telemetry.board_power_while(lambda: time.sleep(0.3), settle_s=0.05)
     assert pw["board_w"] is None
+
+
+def test_member_means_equal_the_reference_call_on_each_block():
+    """harness._member_means (per step and member: the mean reward of the first half of the agents over the member's worlds)
+    == `reward[:, :half].mean()` on that member's (wpm, N, 1) block, as daisy/evo/sges.py:170 forms it - bit for bit: the
+    16-byte gather + contiguous reduction of the N = 4 configuration and the strided reduction of every other shape, for blocks
+    below and above NumPy's pairwise-summation block size."""
+    from therldaisyworld_amd.harness import _member_means
+    rng = np.random.RandomState(2)
+    for trial in range(200):
+        K, P, wpm = int(rng.randint(1, 6)), int(rng.randint(1, 5)), int(rng.choice([1, 3, 4, 32, 33, 70, 300]))
+        N = 4 if trial % 2 else int(rng.randint(1, 9))
+        half = max(1, N // 2)
+        r = rng.rand(K, P * wpm, N, 1) * float(rng.choice([1.0, 1e-3, 1e3]))
+        want = np.array([[r[t, m * wpm:(m + 1) * wpm][:, :half].mean() for m in range(P)] for t in range(K)])
+        assert np.array_equal(_member_means(r, P, wpm, half), want), (trial, K, P, wpm, N)
